@@ -1,0 +1,209 @@
+/*
+ * s5fxp.h -- C ABI of libs5fxp.so: MI355X (gfx950) kernels for the fixed-point S5 inference
+ * path of stevenabreu7/SparseRNNs.
+ *
+ * This is the drop-in boundary.  The reference is pure Python/JAX and has no
+ * FFI of its own, so every entry point below names the reference function it replaces
+ * (file:line into /root/reference/sparseRNNs/).  Conventions:
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses
+ *     (e.g. torch.Tensor.data_ptr()), `stream` is a hipStream_t passed as void*;
+ *   - the caller owns every device buffer; nothing here allocates device memory
+ *     (sizes come from the *_bytes query functions);
+ *   - every call is asynchronous on `stream` and re-entrant (no global mutable state);
+ *   - return value: S5FXP_OK or a negative error code; no exceptions cross the ABI;
+ *   - errors that the reference raises from data-dependent values (a negative shift in
+ *     fxp_mul's "compute_best", fxparray.py:619-621) are reported through a device status
+ *     word, because they are only known on the device.
+ * All tensors are int32, row-major, value = data / 2^exp, exactly as fxparray.py:33-38,157.
+ */
+#ifndef S5FXP_H
+#define S5FXP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S5FXP_VERSION 100
+
+enum {
+    S5FXP_OK = 0,
+    S5FXP_EBADARG = -1,      /* null pointer, non-positive size, unsupported shape */
+    S5FXP_ENEGSHIFT = -2,    /* negative/out-of-range shift: the reference raises ValueError (fxparray.py:619-621)
+                                or hands XLA an undefined shift (fxparray.py:664-667) */
+    S5FXP_EUNSUPPORTED = -3, /* configuration the reference asserts against (fxpmodel.py:429-434,995-999) */
+    S5FXP_EHIP = -4,         /* a HIP runtime call failed */
+    S5FXP_EWORKSPACE = -5    /* workspace or blob too small */
+};
+
+/* rounding modes, fxparray.py:13-17 */
+enum { S5FXP_FLOOR = 0, S5FXP_CEIL = 1, S5FXP_ROUND = 2 };
+
+int s5fxp_version(void);
+const char *s5fxp_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Op level: one entry point per FxpArray primitive the model uses.
+ * ---------------------------------------------------------------------------------------- */
+
+/* fxp_from_fp, fxparray.py:287-307: y = clip(round_mode(x * 2^exp)), x float32. */
+int s5fxp_from_fp(const float *x, int32_t *y, int64_t n, int bits, int exp, int round_mode, void *stream);
+
+/* FxpArray.to_float, fxparray.py:72-73. */
+int s5fxp_to_float(const int32_t *x, float *y, int64_t n, int exp, void *stream);
+
+/* fxp_change_cfg / fxp_change_exp / fxp_clip, fxparray.py:232-271,310-326,346-357 (signed, FLOOR).
+ * Pass new_bits == bits for a pure change_exp; new_exp == exp && new_bits < bits for a pure clip. */
+int s5fxp_change_cfg(const int32_t *x, int32_t *y, int64_t n, int bits, int exp, int new_bits, int new_exp,
+                     void *stream);
+
+/* fxp_matmul (+ the bias fxp_add of FxpDense.forward), fxparray.py:640-678, fxpmodel.py:352-364.
+ * x: (N,K) int32; w: (K,M) int32; bias: (M) int32 or NULL.  y = sat(asr(x@w, x_exp+w_exp-out_exp))
+ * [+ change_exp(bias), sat].  flags bit0: apply ReLU (fxpmodel.py:53-63) to the result. */
+int s5fxp_dense(const int32_t *x, const int32_t *w, const int32_t *bias, int32_t *y, int64_t N, int K, int M,
+                int x_exp, int w_exp, int b_bits, int b_exp, int out_bits, int out_exp, int flags, void *stream);
+
+/* fxp_add with a numeric result_exp, fxparray.py:449-466.  y_len == n (same shape) or a divisor
+ * of n (trailing-axis broadcast, e.g. a bias vector). */
+int s5fxp_add(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_bits, int x_exp,
+              int y_bits, int y_exp, int out_bits, int out_exp, int negate_y, void *stream);
+
+/* fxp_mul with a numeric result_exp, fxparray.py:573-637. */
+int s5fxp_mul(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_exp, int y_exp,
+              int out_bits, int out_exp, void *stream);
+
+/* result_exp="compute_best" forms (fxparray.py:420-448 and 601-609): the exponent is chosen on
+ * the device from float32 maxima over the whole tensor.  `scratch` is >= 16 bytes of device
+ * memory, zeroed by the call; out_exp_dev receives {result_exp, status}.  The host reads it back
+ * (one sync, like the reference's own np.any/int() syncs). */
+int s5fxp_add_cb(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_bits, int x_exp,
+                 int y_bits, int y_exp, int out_bits, int32_t *out_exp_dev, void *scratch, void *stream);
+int s5fxp_mul_cb(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_exp, int y_exp,
+                 int out_bits, int32_t *out_exp_dev, void *scratch, void *stream);
+
+/* fxp_relu, fxpmodel.py:27-63.  im == NULL: real max(x,0).  Otherwise the complex form
+ * (lexicographic maximum(z,0) through float32). */
+int s5fxp_relu(const int32_t *re, const int32_t *im, int32_t *out_re, int32_t *out_im, int64_t n, void *stream);
+
+/* FxpSigmoid.apply, fxpmodel.py:97-144.  lut: 8 host int32 values (fxpmodel.py:89-95). */
+int s5fxp_sigmoid(const int32_t *x, int32_t *y, int64_t n, int x_bits, int x_exp, int sig_x_exp, int sig_y_exp,
+                  const int32_t *lut_host, void *stream);
+
+/* The sequential diagonal-SSM recurrence, fxpmodel.py:147-208 (make_ssm_step_fn / recurrent_loop,
+ * vmapped over the batch at fxpmodel.py:682-704).  bu_*: (B,L,P); a_*: (P); xs_*: (B,L,P).
+ * No clip anywhere; int32 wrap.  flags bit0: apply the complex ReLU to the stored states
+ * (fxpmodel.py:740-742) instead of storing the raw states. */
+int s5fxp_scan(const int32_t *bu_re, const int32_t *bu_im, const int32_t *a_re, const int32_t *a_im, int32_t *xs_re,
+               int32_t *xs_im, int B, int L, int P, int a_re_exp, int a_im_exp, int bu_re_exp, int bu_im_exp,
+               int x_re_exp, int x_im_exp, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model level: FxpRegressionModel.forward, fxpmodel.py:1431-1439 (-> 1261-1271 -> 1110-1161).
+ * The integer parameters are what FxpRegressionModel.export() emits
+ * (fxpmodel.py:368-393,819-847,946-968,1163-1207,1441-1458).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t K, M;
+    const int32_t *weight; /* host, (K,M) */
+    const int32_t *bias;   /* host, (M) */
+    int32_t w_bits, w_exp, b_bits, b_exp, inp_bits, inp_exp, out_bits, out_exp;
+} s5fxp_dense_desc;
+
+typedef struct {
+    int32_t H, P;
+    const int32_t *A_re, *A_im; /* host, (P)   Lambda_bar */
+    const int32_t *B_re, *B_im; /* host, (P,H) B_bar */
+    const int32_t *C_re, *C_im; /* host, (H,P) C_tilde */
+    const int32_t *D;           /* host, (H) */
+    int32_t A_re_bits, A_re_exp, A_im_bits, A_im_exp, B_re_bits, B_re_exp, B_im_bits, B_im_exp;
+    int32_t C_re_bits, C_re_exp, C_im_bits, C_im_exp, D_bits, D_exp;
+    int32_t u_bits, u_exp, Bu_re_bits, Bu_re_exp, Bu_im_bits, Bu_im_exp;
+    int32_t x_re_bits, x_re_exp, x_im_bits, x_im_exp, y_bits, y_exp;
+} s5fxp_ssm_desc;
+
+typedef struct {
+    const int32_t *minus_mean, *invsq_var, *scale, *bias; /* host, (H); scale/bias may be NULL */
+    int32_t mean_bits, mean_exp, invsq_var_bits, invsq_var_exp, scale_bits, scale_exp, bias_bits, bias_exp;
+} s5fxp_norm_desc;
+
+typedef struct {
+    s5fxp_norm_desc norm;
+    s5fxp_ssm_desc ssm;
+    s5fxp_dense_desc out2;
+    int32_t l_bits, l_exp, r_bits, r_exp, res_bits, res_exp; /* mult_gate, fxpmodel.py:1075-1093 */
+    int32_t sig_x_exp, sig_y_exp;                            /* fxpmodel.py:1097-1104 */
+    int32_t lut[8];                                          /* fxpmodel.py:89-95 */
+} s5fxp_layer_desc;
+
+typedef struct {
+    int32_t n_layers;
+    s5fxp_dense_desc encoder;
+    const s5fxp_layer_desc *layers;
+    s5fxp_dense_desc decoder;
+} s5fxp_model_desc;
+
+typedef struct s5fxp_model s5fxp_model; /* opaque host handle */
+
+/* Optional capture of per-layer intermediates (device pointers, any may be NULL); names follow
+ * the reference's sow() keys (fxpmodel.py:653,736,742,793,1120,1126,1135,1145,1153). */
+typedef struct {
+    int32_t *pre_s5;        /* (N,H)  BatchNorm output                       */
+    int32_t *u;             /* (N,H)  SSM input after change_cfg             */
+    int32_t *Bu_re, *Bu_im; /* (N,P)                                         */
+    int32_t *xs_re, *xs_im; /* (N,P)  raw states                             */
+    int32_t *ys;            /* (N,H)  "pre_GLU"                              */
+    int32_t *out2;          /* (N,H)                                         */
+    int32_t *out2_sigmoid;  /* (N,H)                                         */
+    int32_t *post_GLU;      /* (N,H)                                         */
+    int32_t *residadd;      /* (N,H)                                         */
+} s5fxp_layer_trace;
+
+/* Bytes of device memory the packed parameter blob needs. */
+size_t s5fxp_model_blob_bytes(const s5fxp_model_desc *desc);
+
+/* Packs the integer parameters (int8 weights where they fit, CSR for pruned tensors) into
+ * `dev_blob` (device, blob_bytes) with a stream-ordered copy and returns a host handle that keeps
+ * the scalars.  flags: S5FXP_MODEL_* below.  Returns S5FXP_EUNSUPPORTED for shapes outside the
+ * kernels' limits. */
+enum { S5FXP_MODEL_DEFAULT = 0, S5FXP_MODEL_FORCE_DENSE = 1, S5FXP_MODEL_FORCE_CSR = 2, S5FXP_MODEL_FORCE_GENERIC = 4 };
+int s5fxp_model_create(const s5fxp_model_desc *desc, void *dev_blob, size_t blob_bytes, int flags, void *stream,
+                       s5fxp_model **out);
+void s5fxp_model_destroy(s5fxp_model *m);
+
+/* Device workspace for one forward of B sequences of L frames. */
+size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L);
+
+/* Number of int32 words in the device status buffer, and its layout:
+ *   [0] error bits (S5FXP_ST_*), [1] decoder output exponent,
+ *   [8 + 8*l + 0..4] layer l: exponents chosen by the 4 BatchNorm ops and the residual add. */
+#define S5FXP_STATUS_WORDS 128
+enum {
+    S5FXP_ST_NEGSHIFT = 1,   /* a data-dependent shift came out negative: the reference raises ValueError */
+    S5FXP_ST_NEGEXP = 2,     /* a compute_best exponent came out negative (1 << exp fails in the reference) */
+    S5FXP_ST_WIDE_STATE = 4, /* informational: an SSM state exceeded 24 bits, the 32-bit C projection ran */
+    S5FXP_ST_WIDE_INPUT = 8  /* the input tensor holds values beyond 24 bits: results invalid, re-run with a
+                                model created with S5FXP_MODEL_FORCE_GENERIC */
+};
+
+/* Cross-rank hook for the data-dependent exponents (mode A): when not NULL it is
+ * called once per compute_best op, after the local float32 maxima (n <= 4 floats, device memory)
+ * are complete on `stream`, and must leave their element-wise MAX over all ranks in place,
+ * stream-ordered.  NULL = per-shard exponents (mode B). */
+typedef int (*s5fxp_allreduce_max_fn)(void *ctx, float *dev_vals, int n, void *stream);
+
+/* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.
+ * traces: NULL or n_layers entries (host array of device pointers). */
+int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y,
+                        void *workspace, size_t workspace_bytes, int32_t *status, const s5fxp_layer_trace *traces,
+                        s5fxp_allreduce_max_fn allreduce, void *allreduce_ctx, void *stream);
+
+/* Static facts about a created model (for INTEGRATION / debugging). */
+int s5fxp_model_out_exp(const s5fxp_model *m);
+int s5fxp_model_out_bits(const s5fxp_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S5FXP_H */

@@ -1,0 +1,99 @@
+// fxp_prims.hpp -- device-side integer primitives of the fixed-point S5 path (gfx950).
+//
+// Each function states the reference lines it reproduces (paths are into
+// /root/reference/sparseRNNs/).  Everything is int32 with two's-complement wrap, which is
+// what the reference computes under default JAX (x64 disabled).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fxp {
+
+__host__ __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__host__ __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__host__ __device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__host__ __device__ __forceinline__ int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
+__host__ __device__ __forceinline__ int32_t asr(int32_t a, int s) { return a >> s; }
+
+// fxp_clip, fxparray.py:329-334,346-357 (signed).  One v_med3_i32.
+__host__ __device__ __forceinline__ int32_t sat(int32_t v, int bits)
+{
+    const int32_t hi = (int32_t)((1u << (bits - 1)) - 1u);
+    const int32_t lo = ~hi;
+    return v > hi ? hi : (v < lo ? lo : v);
+}
+
+// fxp_change_exp, fxparray.py:310-326: unchanged exponent -> NO clip; otherwise shift and clip
+// at the operand's CURRENT bits.
+__host__ __device__ __forceinline__ int32_t chexp(int32_t d, int bits, int e, int e2)
+{
+    if (e2 == e) return d;
+    return sat(e2 > e ? wshl(d, e2 - e) : asr(d, e - e2), bits);
+}
+
+// fxp_change_cfg, fxparray.py:232-271 (signed, FLOOR).
+__host__ __device__ __forceinline__ int32_t chcfg(int32_t d, int bits, int e, int bits2, int e2)
+{
+    if (bits == bits2 && e == e2) return d;
+    d = chexp(d, bits, e, e2);
+    return bits > bits2 ? sat(d, bits2) : d;
+}
+
+// FxpArray.to_float, fxparray.py:72-73: int32 -> f32 (RNE) then an exact power-of-two scale.
+__device__ __forceinline__ float tofloat(int32_t d, int e) { return ldexpf((float)d, -e); }
+
+// f32 -> s32 as XLA converts: truncate toward zero, saturate (v_cvt_i32_f32 does exactly that).
+__device__ __forceinline__ int32_t f2i(float f) { return (int32_t)f; }
+
+// Complex ReLU, fxpmodel.py:30-45: jax.nn.relu on complex64 == lexicographic maximum(z, 0);
+// both parts round-trip through float32.
+__device__ __forceinline__ void crelu(int32_t &re, int32_t &im)
+{
+    const float fr = (float)re, fi = (float)im;
+    const bool keep = (fr > 0.f) || (fr == 0.f && fi > 0.f);
+    re = keep ? f2i(fr) : 0;
+    im = keep ? f2i(fi) : 0;
+}
+
+// FxpSigmoid.apply + lut_sigmoid_half, fxpmodel.py:97-144.  lut has 8 entries.
+__device__ __forceinline__ int32_t sigmoid_lut(int32_t x, int xbits, int xe, int sx, int sy, const int32_t *lut)
+{
+    const int32_t xx = chexp(x, xbits, xe, sx);
+    const int32_t a = xx < 0 ? wsub(0, xx) : xx;
+    int32_t ind = asr(a, sx);
+    ind = ind > 6 ? 6 : ind;
+    const int32_t mu = a & ((1 << sx) - 1);
+    const int32_t half = wadd(asr(wmul((1 << sx) - mu, lut[ind]), sx), asr(wmul(mu, lut[ind + 1]), sx));
+    return wadd(1 << (sy - 1), xx > 0 ? half : wsub(0, half));
+}
+
+// max(0, int(ceil(log2(m + eps)))) in float32 with a correctly rounded log2 (fxparray.py:421-425,
+// 603-607).  Evaluated by one thread per compute_best op, so the double log2 costs nothing.
+__device__ inline int intbits_f32(float m, float eps)
+{
+    const float v = __fadd_rn(m, eps);
+    const float l = (float)log2((double)v);
+    const int c = (int)ceilf(l);
+    return c > 0 ? c : 0;
+}
+
+// ---- "compute_best" add in device-exponent form (fxparray.py:420-448) ------------------------
+struct AddCb {
+    int32_t shx;  // left shift that brings x to agg_exp (>= 0)
+    int32_t shy;  // same for y
+    int32_t post; // result_exp - agg_exp : > 0 left shift, < 0 arithmetic right shift
+    int32_t eo;   // result_exp
+};
+
+__device__ __forceinline__ int32_t add_cb_apply(int32_t x, int xb, int32_t y, int yb, const AddCb &p, int ob)
+{
+    // change_cfg(op -> max(agg_bits, bits), agg_exp): a left shift saturates at the operand's own
+    // bits (fxparray.py:321-325); the widening afterwards never clips.
+    const int32_t a = p.shx ? sat(wshl(x, p.shx), xb) : x;
+    const int32_t b = p.shy ? sat(wshl(y, p.shy), yb) : y;
+    int32_t s = wadd(a, b);
+    s = p.post > 0 ? wshl(s, p.post) : (p.post < 0 ? asr(s, -p.post) : s);
+    return sat(s, ob);
+}
+
+} // namespace fxp

@@ -1,0 +1,193 @@
+"""Fused forward of the fixed-point S5 model: Python driver of ``s5fxp_model_forward``.
+
+``Engine`` takes the INTEGER model in the reference's ``export()`` layout
+(sparseRNNs/fxpmodel.py:1441-1458 and the nested exports it gathers), hands it to the C ABI,
+and owns the device buffers (parameter blob, workspace, status words) as torch tensors.
+The forward itself is a sequence of HIP kernel launches on the current stream with no host
+synchronisation inside; data-dependent exponents stay in device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (DenseDesc, LayerDesc, LayerTrace, ModelDesc, NormDesc, SSMDesc, TRACE_FIELDS, check, lib)
+from .fxparray import FxpArray
+
+I32P = _lib.I32P
+
+
+class Engine:
+    def __init__(self, export: dict, flags: int = 0, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sparsernns_amd.Engine needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self._keep: list = []
+        P, Q = export["params"], export["qconfig"]
+        self.n_layers = len([k for k in P["encoder"] if k.startswith("layers_")])
+        self._layers = (LayerDesc * max(self.n_layers, 1))()
+        for i in range(self.n_layers):
+            self._fill_layer(self._layers[i], P["encoder"][f"layers_{i}"], Q["encoder"][f"layers_{i}"])
+        self._desc = ModelDesc()
+        self._desc.n_layers = self.n_layers
+        self._desc.encoder = self._dense(P["encoder"]["encoder"], Q["encoder"]["encoder"])
+        self._desc.layers = C.cast(self._layers, C.POINTER(LayerDesc))
+        self._desc.decoder = self._dense(P["decoder"], Q["decoder"])
+        self.d_in, self.H = self._desc.encoder.K, self._desc.encoder.M
+        self.P = self._layers[0].ssm.P if self.n_layers else 0
+        self.d_out = self._desc.decoder.M
+        self.inp_bits, self.inp_exp = self._desc.encoder.inp_bits, self._desc.encoder.inp_exp
+        nbytes = lib.s5fxp_model_blob_bytes(C.byref(self._desc))
+        if nbytes == 0:
+            # let create() report the precise reason
+            nbytes = 256
+        with torch.cuda.device(self.device):
+            self.blob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            handle = C.c_void_p()
+            check(lib.s5fxp_model_create(C.byref(self._desc), self.blob.data_ptr(), nbytes, flags,
+                                         torch.cuda.current_stream().cuda_stream, C.byref(handle)), "s5fxp_model_create")
+        self._h = handle
+        self.out_bits, self.out_exp = lib.s5fxp_model_out_bits(self._h), lib.s5fxp_model_out_exp(self._h)
+        self.status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None
+        self._cb_keep = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.s5fxp_model_destroy(h)
+            self._h = None
+
+    # -- descriptor construction ---------------------------------------------------------------
+    def _ptr(self, a) -> I32P:
+        arr = np.ascontiguousarray(np.asarray(a).astype(np.int64).astype(np.int32))
+        self._keep.append(arr)
+        return arr.ctypes.data_as(I32P)
+
+    def _dense(self, p: dict, q: dict) -> DenseDesc:
+        d = DenseDesc()
+        d.K, d.M = p["weight"].shape
+        d.weight, d.bias = self._ptr(p["weight"]), self._ptr(p["bias"])
+        d.w_bits, d.w_exp = int(q["weight_bits"]), int(q["weight_exp"])
+        d.b_bits, d.b_exp = int(q["bias_bits"]), int(q["bias_exp"])
+        d.inp_bits, d.inp_exp = int(q["inp_bits"]), int(q["inp_exp"])
+        d.out_bits, d.out_exp = int(q["out_bits"]), int(q["out_exp"])
+        return d
+
+    def _fill_layer(self, L: LayerDesc, lp: dict, lq: dict) -> None:
+        L.out2 = self._dense(lp["out2"], lq["out2"])
+        m, mq = lp["mixer"], lq["mixer"]
+        s: SSMDesc = L.ssm
+        s.P, s.H = m["B_real"].shape
+        for f, k in (("A_re", "A_real"), ("A_im", "A_imag"), ("B_re", "B_real"), ("B_im", "B_imag"),
+                     ("C_re", "C_real"), ("C_im", "C_imag"), ("D", "D")):
+            setattr(s, f, self._ptr(m[k]))
+            setattr(s, f + "_bits", int(mq[f"{k}_bits"]))
+            setattr(s, f + "_exp", int(mq[f"{k}_exp"]))
+        for k in ("u", "Bu_re", "Bu_im", "x_re", "x_im", "y"):
+            setattr(s, k + "_bits", int(mq[f"{k}_bits"]))
+            setattr(s, k + "_exp", int(mq[f"{k}_exp"]))
+        n, nq = lp["norm"], lq["norm"]
+        bn: NormDesc = L.norm
+        bn.minus_mean = self._ptr(-np.asarray(n["mean"], dtype=np.int64))  # export() stores +mean (:949)
+        bn.invsq_var = self._ptr(n["invsq_var"])
+        bn.mean_bits, bn.mean_exp = int(nq["mean_bits"]), int(nq["mean_exp"])
+        bn.invsq_var_bits, bn.invsq_var_exp = int(nq["invsq_var_bits"]), int(nq["invsq_var_exp"])
+        if "scale" in n:
+            bn.scale, bn.scale_bits, bn.scale_exp = self._ptr(n["scale"]), int(nq["scale_bits"]), int(nq["scale_exp"])
+        if "bias" in n:
+            bn.bias, bn.bias_bits, bn.bias_exp = self._ptr(n["bias"]), int(nq["bias_bits"]), int(nq["bias_exp"])
+        for k in ("l_bits", "l_exp", "r_bits", "r_exp", "res_bits", "res_exp"):
+            setattr(L, k, int(lq["multgate"][k]))
+        sg = lq["sigmoid"]
+        if int(sg.get("x_extra", 3)) != 3 or int(sg.get("n_exp", 3)) != 3:
+            raise NotImplementedError("only the reference's 8-entry sigmoid LUT is implemented")
+        L.sig_x_exp, L.sig_y_exp = int(sg["x_exp"]), int(sg["y_exp"])
+        from .fxpmodel import sigmoid_lut
+        lut = sigmoid_lut(L.sig_x_exp, L.sig_y_exp)
+        for j in range(8):
+            L.lut[j] = int(lut[j])
+
+    # -- forward ---------------------------------------------------------------------------------
+    def workspace(self, B: int, L: int) -> torch.Tensor:
+        key = (B, L)
+        if self._ws_key != key:
+            n = lib.s5fxp_workspace_bytes(self._h, B, L)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
+                traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None) -> None:
+        """Launches one forward on the current stream; nothing is synchronised."""
+        ws = self.workspace(B, L)
+        tr = None
+        if traces is not None:
+            tr = (LayerTrace * self.n_layers)()
+            for i, d in enumerate(traces):
+                for k in TRACE_FIELDS:
+                    if k in d:
+                        setattr(tr[i], k, d[k].data_ptr())
+        if allreduce is not None:
+            def _cb(ctx, dev_ptr, n, stream):  # noqa: ANN001
+                try:
+                    allreduce(int(dev_ptr), int(n), int(stream) if stream else 0)
+                    return 0
+                except Exception:  # pragma: no cover - surfaced as EHIP by the C side
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.ALLREDUCE_FN(_cb)
+            self._cb_keep = cb
+        else:
+            cb = C.cast(None, _lib.ALLREDUCE_FN)
+        check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), self.status.data_ptr(),
+                                      C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, cb, None,
+                                      torch.cuda.current_stream().cuda_stream), "s5fxp_model_forward")
+
+    def check_status(self) -> np.ndarray:
+        """Reads the status words back (one sync) and raises what the reference would have raised."""
+        st = self.status.cpu().numpy()
+        if st[0] & _lib.ST_NEGSHIFT:
+            raise ValueError("invalid result_exp: a data-dependent shift came out negative (fxparray.py:619-621)")
+        if st[0] & _lib.ST_NEGEXP:
+            raise ValueError("a compute_best exponent came out negative")
+        if st[0] & _lib.ST_WIDE_INPUT:
+            raise OverflowError("input FxpArray holds values beyond 24 bits; rebuild the engine with "
+                                "flags=MODEL_FORCE_GENERIC")
+        return st
+
+    def layer_exponents(self) -> List[Dict[str, int]]:
+        st = self.status.cpu().numpy()
+        names = ("norm_input_minus_mean", "norm_output_raw", "norm_output_scaled", "norm_output_scaled_bias", "residadd")
+        return [{n: int(st[8 + 8 * i + j]) for j, n in enumerate(names)} for i in range(self.n_layers)]
+
+    def forward(self, x: FxpArray, traces: bool = False, allreduce: Optional[Callable] = None, check_status: bool = True):
+        """x: FxpArray (B,L,d_in) or (L,d_in).  Returns an FxpArray (and the traces when asked)."""
+        data = x.data.contiguous()
+        if data.shape[-1] != self.d_in:
+            raise ValueError(f"expected last dim {self.d_in}, got {tuple(data.shape)}")
+        B, L = (1, data.shape[0]) if data.ndim == 2 else (data.shape[0], data.shape[1])
+        y = torch.empty(tuple(data.shape[:-1]) + (self.d_out,), dtype=torch.int32, device=data.device)
+        if B * L == 0:
+            return (FxpArray(y, self.out_bits, self.out_exp, True), []) if traces else FxpArray(y, self.out_bits, self.out_exp, True)
+        tr = None
+        if traces:
+            tr = []
+            for _ in range(self.n_layers):
+                d = {}
+                for k in TRACE_FIELDS:
+                    w = self.P if k in ("Bu_re", "Bu_im", "xs_re", "xs_im") else self.H
+                    d[k] = torch.empty(tuple(data.shape[:-1]) + (w,), dtype=torch.int32, device=data.device)
+                tr.append(d)
+        self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce)
+        if check_status:
+            self.check_status()
+        out = FxpArray(y, self.out_bits, self.out_exp, True)
+        return (out, tr) if traces else out

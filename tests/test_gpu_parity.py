@@ -1,0 +1,253 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical integer inputs.
+
+Bit-exact is the bar: every tensor is int32, so every comparison is array_equal.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cref
+from oracle import fxp_oracle as O
+from sparsernns_amd import synth
+
+TRACE_MAP = dict(pre_s5="pre_s5", u="u", Bu_re="bu_re", Bu_im="bu_im", xs_re="xs_re", xs_im="xs_im", ys="ys",
+                 out2="out2", out2_sigmoid="sigmoid", post_GLU="post_glu", residadd="residadd")
+
+
+def _make(cfg):
+    md, qc, dims = synth.make_model(**cfg)
+    return md, qc, dims
+
+
+def _input(qc, dims, B, L, seed=0, scale=1.0):
+    x = synth.make_input(B, L, dims["d_in"], seed=seed, scale=scale)
+    return O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+
+
+CASES = {
+    "tiny": (dict(dims=synth.tiny_dims()), 3, 50, 1.0),
+    "tiny_bnsb": (dict(dims=synth.tiny_dims(H=12, P=6, d_in=7, d_out=9, n_layers=3), bn_scale_bias=True,
+                       input_scale=30.0), 2, 77, 30.0),
+    "ndns05": (dict(dim_scale=0.5), 2, 200, 1.0),
+    "ndns05_sparse": (dict(dim_scale=0.5, sparsity=0.9), 3, 130, 1.0),
+    "ndns10": (dict(dim_scale=1.0, calib_L=128), 2, 96, 1.0),
+    "ndns05_w4a8": (dict(dim_scale=0.5, quantization="w4a8"), 2, 100, 1.0),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_forward_matches_oracle(name):
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    cfg, B, L, scale = CASES[name]
+    md, qc, dims = _make(cfg)
+    model = build_regression_model(md, qc, dims["n_layers"])
+    fx = _input(qc, dims, B, L, seed=5, scale=scale)
+    cm = cref.CModel(model.export())
+    ref, rb, re_, rtr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+    eng = model.engine()
+    y, tr = eng.forward(FxpArray(fx.data, fx.bits, fx.exp), traces=True)
+    exps = eng.layer_exponents()
+    for i in range(dims["n_layers"]):
+        assert exps[i]["residadd"] == rtr[i]["residadd_exp"], (i, exps[i], rtr[i]["residadd_exp"])
+        for k, ck in TRACE_MAP.items():
+            got = tr[i][k].cpu().numpy()
+            assert np.array_equal(got, rtr[i][ck]), f"layer {i} {k}: {np.count_nonzero(got != rtr[i][ck])} mismatches"
+    assert (y.bits, y.exp) == (rb, re_)
+    assert np.array_equal(y.numpy(), ref)
+    # same result without traces (the production path) and for a 2-D (L, d_in) input
+    y2 = model(FxpArray(fx.data, fx.bits, fx.exp))
+    assert np.array_equal(y2.numpy(), ref)
+
+
+def test_two_d_input_and_ragged_tail():
+    """(L, d_in) input as run_verification uses (fxprun.py:531-549); L not a multiple of the tile."""
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    cm = cref.CModel(model.export())
+    for L in (1, 63, 65):
+        fx = _input(qc, dims, 1, L, seed=L)
+        x2 = fx.data[0]
+        ref, _, _, _ = cm.forward(x2, fx.bits, fx.exp)
+        y = model(FxpArray(x2, fx.bits, fx.exp))
+        assert y.shape == (L, dims["d_out"])
+        assert np.array_equal(y.numpy(), ref)
+
+
+def test_eager_matches_fused_and_names_intermediates():
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dims=synth.tiny_dims(H=12, P=6, d_in=7, d_out=9, n_layers=2), bn_scale_bias=True,
+                              input_scale=30.0))
+    fx = _input(qc, dims, 2, 40, seed=1, scale=30.0)
+    fused = build_regression_model(md, qc, dims["n_layers"])
+    eager = build_regression_model(md, qc, dims["n_layers"], store_intermediates=True)
+    yf = fused(FxpArray(fx.data, fx.bits, fx.exp))
+    ye = eager(FxpArray(fx.data, fx.bits, fx.exp))
+    assert (yf.bits, yf.exp) == (ye.bits, ye.exp)
+    assert np.array_equal(yf.numpy(), ye.numpy())
+    # the numpy oracle names the same stages
+    om = O.RegressionModel(md, qc, dims["n_layers"])
+    inter = {}
+    yo = om(fx, inter)
+    assert np.array_equal(yo.data, ye.numpy())
+    l0 = eager.encoder.seq_layers[0]
+    for key in ("ssm_input", "pre_s5", "pre_C", "pre_GLU", "out2_sigmoid", "post_GLU", "residadd", "output"):
+        assert key in l0.intermediates, key
+    for key in ("Bu_elements", "xs", "xs_relu", "Cxs", "2Cxs", "Du", "ys"):
+        assert key in l0.mixer.intermediates, key
+    for key in ("norm_input", "norm_input_minus_mean", "norm_output_raw", "norm_output_scaled",
+                "norm_output_scaled_bias", "norm_output"):
+        assert key in l0.norm.intermediates, key
+    fl = O.flatten_intermediates(inter)
+    chk = {"layers_0.norm.norm_input_minus_mean": l0.norm.intermediates["norm_input_minus_mean"][-1],
+           "layers_0.norm.norm_output_scaled": l0.norm.intermediates["norm_output_scaled"][-1],
+           "layers_0.mixer.Cxs": l0.mixer.intermediates["Cxs"][-1],
+           "layers_0.mixer.Cxs2": l0.mixer.intermediates["2Cxs"][-1],
+           "layers_0.mixer.Du": l0.mixer.intermediates["Du"][-1],
+           "layers_0.residadd": l0.intermediates["residadd"][-1]}
+    for k, got in chk.items():
+        assert (got.bits, got.exp) == (fl[k].bits, fl[k].exp), k
+        assert np.array_equal(got.numpy(), fl[k].data), k
+    data = eager.export()
+    assert set(data) == {"params", "qconfig", "intermediates"}
+    assert "pre_encoder" in data["intermediates"]["encoder"]
+
+
+# ------------------------------------------------------------------------------------------
+# op level
+# ------------------------------------------------------------------------------------------
+def _rand(rng, shape, bits):
+    return rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=shape, dtype=np.int64).astype(np.int32)
+
+
+def test_ops_match_numpy_oracle():
+    from sparsernns_amd import fxparray as G
+
+    rng = np.random.default_rng(0)
+    a = _rand(rng, (3, 37, 24), 16)
+    b = _rand(rng, (3, 37, 24), 16)
+    v = _rand(rng, (24,), 16)
+    A, B, V = G.FxpArray(a, 16, 12), G.FxpArray(b, 16, 9), G.FxpArray(v, 16, 14)
+    oa, ob, ov = O.Fx(a, 16, 12), O.Fx(b, 16, 9), O.Fx(v, 16, 14)
+
+    def same(g, o):
+        assert (g.bits, g.exp) == (o.bits, o.exp), ((g.bits, g.exp), (o.bits, o.exp))
+        assert np.array_equal(g.numpy(), o.data)
+
+    same(G.fxp_add(A, B, result_bits=16, result_exp=10), O.add(oa, ob, 16, 10))
+    same(G.fxp_add(A, B, result_bits=16, result_exp=13), O.add(oa, ob, 16, 13))
+    same(G.fxp_add(A, V, result_bits=16, result_exp=12), O.add(oa, ov, 16, 12))
+    same(G.fxp_sub(A, B, result_bits=16, result_exp=9), O.sub(oa, ob, 16, 9))
+    same(G.fxp_add(A, B, result_exp="compute_best"), O.add(oa, ob, None, "compute_best"))
+    same(G.fxp_add(A, V, result_exp="compute_best"), O.add(oa, ov, None, "compute_best"))
+    same(G.fxp_mul(A, V, result_exp="compute_best"), O.mul(oa, ov, None, "compute_best"))
+    same(G.fxp_mul(A, B, result_bits=16, result_exp=8), O.mul(oa, ob, 16, 8))
+    same(G.fxp_mul(V, A, result_bits=16, result_exp=11), O.mul(ov, oa, 16, 11))
+    same(G.fxp_change_cfg(A, 12, 8, True), O.change_cfg(oa, 12, 8, True))
+    same(G.fxp_change_cfg(A, 20, 15, True), O.change_cfg(oa, 20, 15, True))
+    same(G.fxp_change_exp(A, 14), O.change_exp(oa, 14))
+    same(G.fxp_change_exp(A, 12), O.change_exp(oa, 12))
+    with pytest.raises(ValueError):
+        G.fxp_mul(A, B, result_bits=16, result_exp=30)
+    # int32 wrap in mul and the unclipped pass-through of change_exp
+    big = _rand(rng, (1000,), 32)
+    same(G.fxp_mul(G.FxpArray(big, 32, 4), G.FxpArray(big[::-1].copy(), 32, 3), result_bits=32, result_exp=2),
+         O.mul(O.Fx(big, 32, 4), O.Fx(big[::-1].copy(), 32, 3), 32, 2))
+    same(G.fxp_clip(G.FxpArray(big, 16, 4)), O.Fx(O.sat(big, 16), 16, 4))
+    # from_fp in the three rounding modes incl. ties
+    xf = np.concatenate([rng.normal(0, 3, 5000), np.arange(-40, 40) / 16.0 + 1 / 32.0]).astype(np.float32)
+    for mode, om in ((G.RoundingMode.FLOOR, O.FLOOR), (G.RoundingMode.ROUND, O.ROUND), (G.RoundingMode.CEIL, O.CEIL)):
+        same(G.fxp_from_fp(xf, 8, 4, True, mode), O.from_fp(xf, 8, 4, True, om))
+    g = G.FxpArray(a, 16, 12).to_float().cpu().numpy()
+    assert np.array_equal(g, oa.f32())
+
+
+def test_matmul_generic_wraps_like_int32():
+    from sparsernns_amd import fxparray as G
+
+    rng = np.random.default_rng(1)
+    for (N, K, M) in ((130, 257, 96), (64, 64, 257), (5, 3, 1), (70, 96, 128)):
+        x = _rand(rng, (N, K), 32)  # full-range operands: the accumulation must wrap modulo 2^32
+        w = _rand(rng, (K, M), 32)
+        got = G.fxp_matmul(G.FxpArray(x, 32, 10), G.FxpArray(w, 32, 5), result_bits=24, result_exp=9)
+        ref = O.matmul(O.Fx(x, 32, 10), O.Fx(w, 32, 5), 24, 9)
+        assert np.array_equal(got.numpy(), ref.data)
+    x = _rand(rng, (2, 33, 40), 16)
+    w = _rand(rng, (40, 12), 8)
+    got = G.fxp_matmul(G.FxpArray(x, 16, 12), G.FxpArray(w, 8, 7), result_bits=16, result_exp=11)
+    assert np.array_equal(got.numpy(), O.matmul(O.Fx(x, 16, 12), O.Fx(w, 8, 7), 16, 11).data)
+
+
+def test_scan_and_relu_edge_cases():
+    import torch
+    from sparsernns_amd import fxparray as G
+    from sparsernns_amd._lib import check, lib
+    from sparsernns_amd.fxpmodel import fxp_relu
+
+    rng = np.random.default_rng(2)
+    for (B, L, P, bits, ea, sh) in ((3, 70, 5, 16, 15, 1), (2, 33, 64, 16, 15, -2), (1, 1, 1, 16, 12, 0),
+                                    (2, 50, 7, 30, 15, 1)):  # the last one overflows int32 in A*x: wrap must match
+        bre, bim = _rand(rng, (B, L, P), bits), _rand(rng, (B, L, P), bits)
+        ar, ai = _rand(rng, (P,), 16), _rand(rng, (P,), 16)
+        e_bu, e_x = 15, 15 - sh
+        orr, oi = O.scan(O.Fx(bre, 16, e_bu), O.Fx(bim, 16, e_bu), O.Fx(ar, 16, ea), O.Fx(ai, 16, ea), e_x, e_x)
+        t = lambda a: torch.as_tensor(a).cuda()
+        dbre, dbim, dar, dai = t(bre), t(bim), t(ar), t(ai)
+        for flags in (0, 1):
+            xr, xi = torch.empty_like(dbre), torch.empty_like(dbim)
+            check(lib.s5fxp_scan(dbre.data_ptr(), dbim.data_ptr(), dar.data_ptr(), dai.data_ptr(), xr.data_ptr(),
+                                 xi.data_ptr(), B, L, P, ea, ea, e_bu, e_bu, e_x, e_x, flags,
+                                 torch.cuda.current_stream().cuda_stream))
+            if flags:
+                er, ei = O.complex_relu(O.Fx(orr, 16, e_x), O.Fx(oi, 16, e_x))
+                er, ei = er.data, ei.data
+            else:
+                er, ei = orr, oi
+            assert np.array_equal(xr.cpu().numpy(), er) and np.array_equal(xi.cpu().numpy(), ei)
+    # complex ReLU truth table incl. float32 round trip of wide values
+    re = np.array([5, 0, 0, 0, -3, 2**24 + 1, -(2**24) - 1, 7, 2**31 - 1], dtype=np.int64).astype(np.int32)
+    im = np.array([-9, 4, 0, -4, 8, 2**24 + 3, 5, 2**30 + 1, -(2**31)], dtype=np.int64).astype(np.int32)
+    out = fxp_relu(G.ComplexFxpArray(G.FxpArray(re, 16, 3), G.FxpArray(im, 16, 3)))
+    er, ei = O.complex_relu(O.Fx(re, 16, 3), O.Fx(im, 16, 3))
+    assert np.array_equal(out.real.numpy(), er.data) and np.array_equal(out.imag.numpy(), ei.data)
+
+
+def test_sigmoid_lut_all_inputs():
+    from sparsernns_amd import fxparray as G
+    from sparsernns_amd.fxpmodel import FxpSigmoid
+
+    allv = np.arange(-(1 << 15), 1 << 15, dtype=np.int32)
+    for (xe_in, bits) in ((12, 16), (6, 16), (4, 16), (9, 8)):
+        x_exp, y_exp = min(xe_in, 6), bits - 2
+        s = FxpSigmoid(x_exp=x_exp, y_exp=y_exp)
+        lut = O.sigmoid_lut(x_exp, y_exp)
+        assert np.array_equal(s.lut, lut)
+        v = allv if bits == 16 else np.arange(-128, 128, dtype=np.int32)
+        got = s.apply(G.FxpArray(v, bits, xe_in))
+        ref = O.sigmoid_apply(O.Fx(v, bits, xe_in), x_exp, y_exp, lut)
+        assert (got.bits, got.exp) == (ref.bits, ref.exp)
+        assert np.array_equal(got.numpy(), ref.data)
+
+
+def test_compute_best_thresholds_near_powers_of_two():
+    """ceil(log2(max + eps)) either side of powers of two: GPU finalize == oracle definition."""
+    from sparsernns_amd import fxparray as G
+
+    for k in range(0, 15):
+        for delta in (-2, -1, 0, 1, 2, 3, 6):
+            v = (1 << k) * 64 + delta  # value/2^6 sits next to 2^k
+            if v <= 0 or v >= (1 << 23):
+                continue
+            a = np.array([v, -3, 0, 1], dtype=np.int32)
+            z = np.zeros(4, dtype=np.int32)
+            got = G.fxp_add(G.FxpArray(a, 24, 6), G.FxpArray(z, 24, 6), result_exp="compute_best")
+            ref = O.add(O.Fx(a, 24, 6), O.Fx(z, 24, 6), None, "compute_best")
+            assert got.exp == ref.exp, (k, delta, got.exp, ref.exp)
+            assert np.array_equal(got.numpy(), ref.data)
