@@ -287,7 +287,18 @@ def make_model(dim_scale: float = 0.5, seed: int = 1919, quantization: str = "w8
     xcal = make_input(calib_B, calib_L, dims["d_in"], seed=seed + 1, scale=input_scale)
     float_forward(md, xcal, dims["n_layers"], calibrate_bn=(bn_stats == "calibrated"), stats=stats)
     qc = derive_qconfig(md, stats, dims["n_layers"], PRECISIONS[quantization])
+    _assert_exps_nonnegative(qc)
     return md, qc, dims
+
+
+def _assert_exps_nonnegative(tree, path="fxp_qconfig"):
+    """A negative exponent is not representable in the reference (``1 << exp``, fxparray.py:73)."""
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            _assert_exps_nonnegative(v, f"{path}.{k}")
+        elif (k == "exp" or k.endswith("_exp")) and v < 0:
+            raise ValueError(f"{path}.{k} = {v} < 0: this synthetic configuration does not fit the chosen bit widths "
+                             "(try bn_stats='random' or a larger input_scale)")
 
 
 def tiny_dims(H: int = 8, P: int = 4, d_in: int = 5, d_out: int = 5, n_layers: int = 2) -> dict:

@@ -32,7 +32,7 @@ CASES = {
     "ndns05": (dict(dim_scale=0.5), 2, 200, 1.0),
     "ndns05_sparse": (dict(dim_scale=0.5, sparsity=0.9), 3, 130, 1.0),
     "ndns10": (dict(dim_scale=1.0, calib_L=128), 2, 96, 1.0),
-    "ndns05_w4a8": (dict(dim_scale=0.5, quantization="w4a8"), 2, 100, 1.0),
+    "ndns05_w4a8": (dict(dim_scale=0.5, quantization="w4a8", bn_stats="random", input_scale=300.0), 2, 100, 300.0),
 }
 
 
