@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the fixed-point S5 forward (w8a16, dim_scale=0.5, NDNS shape) on MI355X.
+
+One "step" = one fused forward (encoder -> 3 S5 layers -> decoder, int32 in -> int32 out) over one
+batch of synthetic NDNS-shaped sequences that is already resident in HBM.  Workload = BASELINE.json
+configs[1]: B=32 sequences x L=4096 frames per GPU, dense (un-pruned) w8a16.
+
+  python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run)
+
+Multi-GPU: every rank runs whole reference batches of its own (per-shard exponents: exactly what
+the reference computes for that batch, SURVEY.md §8e mode B), no data-path collective; weak scaling.
+An RCCL all_gather of the outputs is exercised once outside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the round prompt), with `roofline` for the recurrence
+kernel (timed in situ with HIP events on the launch stream) and `cpu_baseline` (the scalar C oracle
+on the host cores; a reported baseline, not the thing measured).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU")
+    ap.add_argument("--seq-len", type=int, default=4096)
+    ap.add_argument("--dim-scale", type=float, default=0.5)
+    ap.add_argument("--sparsity", type=float, default=0.0)
+    ap.add_argument("--quantization", default="w8a16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="sequences in the bounded CPU-baseline sample")
+    ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as graft
+    graft.build()
+    from sparsernns_amd import synth
+    from sparsernns_amd.fxparray import FxpArray, RoundingMode, fxp_from_fp
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    B, L = args.batch, args.seq_len
+    md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity)
+    allreduce = None
+    if args.global_exponents and world > 1:
+        from sparsernns_amd.dist import make_exponent_allreduce
+        allreduce = make_exponent_allreduce()
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    x = synth.make_input(B, L, dims["d_in"], seed=1000 + rank)  # every rank its own batch
+    fx = fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
+                     round_mode=RoundingMode.FLOOR)
+    xin = fx.data
+    y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device=dev)
+    n_ev = 2 * dims["n_layers"]
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 0)):
+        eng.enqueue(xin, fx.bits, fx.exp, y, B, L, None, allreduce)
+    torch.cuda.synchronize()
+    eng.check_status()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
+    for evs in events:  # torch creates the hipEvent lazily on the first record(); the C side needs the handle
+        for e in evs:
+            e.record()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.enqueue(xin, fx.bits, fx.exp, y, B, L, None, allreduce, scan_events=events[k])
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = eng.check_status()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = B * L * world * args.steps
+    value = frames / dt
+
+    # ---- roofline of the dominant kernel (the recurrence): algorithmic bytes = 16*P per frame per layer
+    scan_ms = [events[k][2 * l].elapsed_time(events[k][2 * l + 1]) for k in range(args.steps)
+               for l in range(dims["n_layers"])]
+    scan_avg_s = float(np.mean(scan_ms)) * 1e-3
+    algo_bytes = B * L * dims["P"] * 16
+    achieved = algo_bytes / scan_avg_s / 1e9
+    roofline = dict(bound="hbm", kernel="scan", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    avg_kernel_us=round(scan_avg_s * 1e6, 2), algorithmic_bytes_per_launch=algo_bytes)
+
+    # ---- RCCL output gather, exercised once outside the timed region
+    gather_ms = None
+    if dist is not None:
+        out = torch.empty((world,) + tuple(y.shape), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, y)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert torch.equal(out[rank], y)
+
+    # ---- CPU baseline: the scalar C oracle ("port") on a bounded sample of the same workload, rank 0 only
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import cref
+        cb = min(args.cpu_batch, B)
+        cm = cref.CModel(model.export())
+        xs_host = fx.data[:cb].cpu().numpy()
+        c0 = time.perf_counter()
+        ref, _, _, _ = cm.forward(xs_host, fx.bits, fx.exp)
+        cdt = time.perf_counter() - c0
+        same = bool(np.array_equal(ref, y[:cb].cpu().numpy())) if cb == B else None
+        cpu = dict(value=round(cb * L / cdt, 1), unit="frames/s", cores=cref.num_threads(), kind="port",
+                   sample=f"{cb} sequences x {L} frames of the same workload, one pass, OpenMP scalar C restatement "
+                          f"(oracle/s5fxp_ref.c); the reference's JAX path is not installable offline",
+                   seconds=round(cdt, 2), matches_gpu=same)
+
+    if rank == 0:
+        line = dict(
+            metric="frames/sec at w8a16 S5 dim_scale=0.5 (NDNS shape), bit-exact vs CPU fxprun",
+            value=round(value, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+            dtype="int32 (w8a16 fixed point)", data="synthetic",
+            config=dict(workload=f"BASELINE configs[1]: dim_scale={args.dim_scale} {args.quantization} "
+                                 f"{'dense' if args.sparsity == 0 else f'{args.sparsity:.0%} sparse'} S5, "
+                                 f"B={B} x L={L} per GPU, H={dims['H']}, P={dims['P']}, 3 layers, d_in=d_out=257",
+                        batch_per_gpu=B, seq_len=L, exponent_mode="global (all-reduce MAX)" if allreduce else "per-shard",
+                        parallelism=f"batch-sharded x{world}"),
+            roofline=roofline, cpu_baseline=cpu, status_bits=int(st[0]), output_gather_ms=gather_ms)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -193,11 +193,20 @@ enum {
  * stream-ordered.  NULL = per-shard exponents (mode B). */
 typedef int (*s5fxp_allreduce_max_fn)(void *ctx, float *dev_vals, int n, void *stream);
 
+/* Optional knobs of one forward (all-zero = defaults). */
+typedef struct {
+    s5fxp_allreduce_max_fn allreduce; /* NULL: per-shard exponents */
+    void *allreduce_ctx;
+    /* Measurement only: 2*n_layers hipEvent_t handles (or NULL); events [2l] / [2l+1] are recorded on
+     * `stream` immediately before / after layer l's recurrence kernel(s). */
+    void **scan_events;
+} s5fxp_forward_opts;
+
 /* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.
- * traces: NULL or n_layers entries (host array of device pointers). */
+ * traces: NULL or n_layers entries (host array of device pointers); opts: NULL or see above. */
 int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y,
                         void *workspace, size_t workspace_bytes, int32_t *status, const s5fxp_layer_trace *traces,
-                        s5fxp_allreduce_max_fn allreduce, void *allreduce_ctx, void *stream);
+                        const s5fxp_forward_opts *opts, void *stream);
 
 /* Static facts about a created model (for INTEGRATION / debugging). */
 int s5fxp_model_out_exp(const s5fxp_model *m);

@@ -64,6 +64,10 @@ class LayerTrace(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, VOIDP, VOIDP, C.c_int, VOIDP)
 
 
+class ForwardOpts(C.Structure):
+    _fields_ = [("allreduce", ALLREDUCE_FN), ("allreduce_ctx", VOIDP), ("scan_events", C.POINTER(VOIDP))]
+
+
 class S5FxpError(RuntimeError):
     pass
 
@@ -93,7 +97,7 @@ def _load():
         "s5fxp_model_create": (i, [C.POINTER(ModelDesc), p, C.c_size_t, i, p, C.POINTER(p)]),
         "s5fxp_model_destroy": (None, [p]),
         "s5fxp_workspace_bytes": (C.c_size_t, [p, i, i]),
-        "s5fxp_model_forward": (i, [p, p, i, i, i, i, p, p, C.c_size_t, p, C.POINTER(LayerTrace), ALLREDUCE_FN, p, p]),
+        "s5fxp_model_forward": (i, [p, p, i, i, i, i, p, p, C.c_size_t, p, C.POINTER(LayerTrace), C.POINTER(ForwardOpts), p]),
         "s5fxp_model_out_exp": (i, [p]),
         "s5fxp_model_out_bits": (i, [p]),
     }

@@ -5,6 +5,7 @@
 #include "../../include/s5fxp.h"
 #include "s5fxp_kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -42,14 +43,14 @@ constexpr int MW_LIMIT = 68;
     } while (0)
 
 // k_cproj keeps two output tiles in LDS; its column budget stops at 48 (H <= 192)
-#define S5_DISPATCH_MW_C(mw, X24, grid, stream, args)                                                         \
+#define S5_DISPATCH_MW_C(mw, X24, PASS, grid, stream, args)                                                         \
     do {                                                                                                      \
-        if ((mw) <= 4) hipLaunchKernelGGL((k_cproj<4, X24>), dim3(grid), dim3(256), 0, stream, args);         \
-        else if ((mw) <= 8) hipLaunchKernelGGL((k_cproj<8, X24>), dim3(grid), dim3(256), 0, stream, args);    \
-        else if ((mw) <= 16) hipLaunchKernelGGL((k_cproj<16, X24>), dim3(grid), dim3(256), 0, stream, args);  \
-        else if ((mw) <= 24) hipLaunchKernelGGL((k_cproj<24, X24>), dim3(grid), dim3(256), 0, stream, args);  \
-        else if ((mw) <= 32) hipLaunchKernelGGL((k_cproj<32, X24>), dim3(grid), dim3(256), 0, stream, args);  \
-        else hipLaunchKernelGGL((k_cproj<48, X24>), dim3(grid), dim3(256), 0, stream, args);                  \
+        if ((mw) <= 4) hipLaunchKernelGGL((k_cproj<4, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);         \
+        else if ((mw) <= 8) hipLaunchKernelGGL((k_cproj<8, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);    \
+        else if ((mw) <= 16) hipLaunchKernelGGL((k_cproj<16, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
+        else if ((mw) <= 24) hipLaunchKernelGGL((k_cproj<24, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
+        else if ((mw) <= 32) hipLaunchKernelGGL((k_cproj<32, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
+        else hipLaunchKernelGGL((k_cproj<48, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);                  \
     } while (0)
 constexpr int MW_LIMIT_C = 48;
 
@@ -228,8 +229,8 @@ extern "C" int s5fxp_scan(const int32_t *bu_re, const int32_t *bu_im, const int3
     if (B == 0 || L == 0) return S5FXP_OK;
     ScanArgs a{};
     a.bu_re = bu_re; a.bu_im = bu_im; a.a_re = a_re; a.a_im = a_im; a.out_re = xs_re; a.out_im = xs_im;
-    a.B = B; a.L = L; a.P = P; a.ea_re = a_re_exp; a.ea_im = a_im_exp; a.sh_re = sr; a.sh_im = si;
-    a.relu = flags & 1;
+    a.B = B; a.L = L; a.P = P; a.TB = 0; a.ea_re = a_re_exp; a.ea_im = a_im_exp; a.sh_re = sr; a.sh_im = si;
+    a.relu = flags & 1; a.run_if = nullptr;
     return launch_scan(a, S(stream));
 }
 
@@ -251,6 +252,8 @@ struct LayerDev {
     const int32_t *a_re = nullptr, *a_im = nullptr, *bcat = nullptr, *c_re_t = nullptr, *c_im_t = nullptr, *D = nullptr;
     s5fxp_ssm_desc sd{};
     bool b24 = false, c24 = false;
+    bool quad_ok = false; // quad recurrence kernel applicable (P % 16 == 0, coefficients fit 24 bits)
+    int32_t quad_xmax = 0; // its exactness bound on |state|
     DenseDev out2;
     int l_bits, l_exp, r_bits, r_exp, res_bits, res_exp, sig_x, sig_y;
     int32_t lut[8];
@@ -320,6 +323,21 @@ void pack_layer(Packer &p, const s5fxp_layer_desc &l, LayerDev &o, bool allow24)
     o.c_im_t = p.put(t3.data(), t3.size());
     o.c24 = allow24 && fits24(t2.data(), t2.size()) && fits24(t3.data(), t3.size());
     o.D = p.put(l.ssm.D, H);
+    {
+        // scaled coefficients c = A * 2^(16-e) must fit 24 signed bits; |c*x| + 2^16 < 2^31 bounds the state
+        const int sre = 16 - l.ssm.A_re_exp, sim = 16 - l.ssm.A_im_exp;
+        int64_t cmax = 1;
+        for (int q = 0; q < P; ++q) {
+            const int64_t ar = std::llabs((long long)l.ssm.A_re[q]), ai = std::llabs((long long)l.ssm.A_im[q]);
+            const int smax = sre > sim ? sre : sim;
+            if (smax >= 0 && smax < 24) {
+                cmax = std::max(cmax, ar << smax);
+                cmax = std::max(cmax, ai << smax);
+            }
+        }
+        o.quad_ok = allow24 && (P % 16 == 0) && sre >= 0 && sim >= 0 && sre < 16 && sim < 16 && cmax < (1 << 23);
+        o.quad_xmax = (int32_t)std::min<int64_t>(((int64_t(1) << 31) - 1 - 65536) / cmax, (1 << 23) - 1);
+    }
     pack_dense(p, l.out2, o.out2, allow24);
     o.l_bits = l.l_bits; o.l_exp = l.l_exp; o.r_bits = l.r_bits; o.r_exp = l.r_exp; o.res_bits = l.res_bits;
     o.res_exp = l.res_exp; o.sig_x = l.sig_x_exp; o.sig_y = l.sig_y_exp;
@@ -419,22 +437,26 @@ extern "C" int s5fxp_model_out_exp(const s5fxp_model *m) { return m ? m->dec.out
 extern "C" int s5fxp_model_out_bits(const s5fxp_model *m) { return m ? m->dec.out_bits : 0; }
 
 namespace {
+constexpr int SCAN_DEPTH = S5_SCAN_ASM_DEPTH; // time blocks (4 steps each) the quad recurrence kernel keeps in flight
+
 struct WsLayout {
-    size_t hA, hB, bu_re, bu_im, xr, xi, x1, z, dyn, total;
+    size_t hA, hB, bq, xs, x1, z, dyn, total;
+    int TB; // time blocks per sequence in the scan-native streams (padded to a multiple of SCAN_DEPTH)
 };
 WsLayout ws_layout(const s5fxp_model *m, int B, int L)
 {
     const size_t N = (size_t)B * L;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WsLayout w{};
+    w.TB = ((L + 3) / 4 + SCAN_DEPTH - 1) / SCAN_DEPTH * SCAN_DEPTH;
     size_t off = 0;
-    const size_t nh = al(N * m->H * 4), np = al(N * (m->P ? m->P : 1) * 4);
+    const size_t nh = al(N * m->H * 4);
+    // + SCAN_DEPTH blocks of padding: the recurrence kernel's ring buffer reads ahead of the last block
+    const size_t ns = al(((size_t)B * w.TB + SCAN_DEPTH) * (m->P ? m->P : 1) * 8 * 4);
     w.hA = off; off += nh;
     w.hB = off; off += nh;
-    w.bu_re = off; off += np;
-    w.bu_im = off; off += np;
-    w.xr = off; off += np;
-    w.xi = off; off += np;
+    w.bq = off; off += ns;
+    w.xs = off; off += ns;
     w.x1 = off; off += nh;
     w.z = off; off += nh;
     w.dyn = off; off += al(sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1));
@@ -451,10 +473,12 @@ extern "C" size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L)
 
 extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L,
                                    int32_t *y, void *workspace, size_t workspace_bytes, int32_t *status,
-                                   const s5fxp_layer_trace *traces, s5fxp_allreduce_max_fn allreduce,
-                                   void *allreduce_ctx, void *stream)
+                                   const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, void *stream)
 {
     if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
+    s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
+    void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
+    void **scan_events = opts ? opts->scan_events : nullptr;
     const WsLayout w = ws_layout(m, B, L);
     if (workspace_bytes < w.total) return S5FXP_EWORKSPACE;
     hipStream_t st = S(stream);
@@ -525,42 +549,58 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             hipLaunchKernelGGL(k_bn_finalize<4>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
         }
 
-        // ---- B projection (fused BatchNorm apply + change_cfg)
+        // ---- B projection (fused BatchNorm apply + change_cfg), writes the scan-native stream
+        const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
         {
             BprojArgs a{};
-            a.bn = bn; a.x = h; a.w = l.bcat; a.bu_re = I(w.bu_re); a.bu_im = I(w.bu_im);
+            a.bn = bn; a.x = h; a.w = l.bcat; a.bq = I(w.bq);
+            a.tr_bu_re = tr ? tr->Bu_re : nullptr; a.tr_bu_im = tr ? tr->Bu_im : nullptr;
             a.tr_pre_s5 = tr ? tr->pre_s5 : nullptr; a.tr_u = tr ? tr->u : nullptr;
-            a.N = N; a.H = H; a.P = P; a.mw = mw_for(2 * P);
+            a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P; a.mw = mw_for(2 * P);
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
-            a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits;
+            a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
             if (l.b24 && s.u_bits <= 24 && bn.out_bits <= 24) S5_DISPATCH_MW(a.mw, true, k_bproj, tiles, st, a);
             else S5_DISPATCH_MW(a.mw, false, k_bproj, tiles, st, a);
-            if (tr && tr->Bu_re)
-                hipMemcpyAsync(tr->Bu_re, a.bu_re, (size_t)N * P * 4, hipMemcpyDeviceToDevice, st);
-            if (tr && tr->Bu_im)
-                hipMemcpyAsync(tr->Bu_im, a.bu_im, (size_t)N * P * 4, hipMemcpyDeviceToDevice, st);
         }
-        // ---- recurrence + complex ReLU
-        {
-            ScanArgs a{};
-            a.bu_re = I(w.bu_re); a.bu_im = I(w.bu_im); a.a_re = l.a_re; a.a_im = l.a_im;
-            a.out_re = I(w.xr); a.out_im = I(w.xi);
-            a.raw_re = tr ? tr->xs_re : nullptr; a.raw_im = tr ? tr->xs_im : nullptr;
-            a.B = B; a.L = L; a.P = P; a.ea_re = s.A_re_exp; a.ea_im = s.A_im_exp;
-            a.sh_re = s.Bu_re_exp - s.x_re_exp; a.sh_im = s.Bu_im_exp - s.x_im_exp;
-            a.relu = 1; a.wide = &d->wide; a.status = status;
-            if ((rc = launch_scan(a, st))) return rc;
+        // ---- recurrence.  Fast: quad kernel (3 dependent VALU ops / step), exact while |x| <= xmax; the C
+        //      projection checks that bound on every state and, if it fails, the exact 32-bit kernels re-run.
+        ScanArgs sl{};
+        sl.bu_re = I(w.bq); sl.a_re = l.a_re; sl.a_im = l.a_im; sl.out_re = I(w.xs);
+        sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
+        const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
+        int32_t xmax = (1 << 23) - 1; // the 24-bit C projection's own limit
+        const bool quad = l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC);
+        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
+        if (quad) {
+            ScanQuadArgs q{};
+            q.bq = I(w.bq); q.xs = I(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+            xmax = l.quad_xmax;
+        } else {
+            sl.run_if = nullptr;
+            hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
         }
-        // ---- C projection + D*u + ReLU (both precisions are enqueued; LayerDyn::wide selects)
+        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
+        // ---- C projection + D*u + ReLU: pass 0 (24-bit multiplies, range check), then the exact re-run
         {
             CprojArgs a{};
-            a.bn = bn; a.x = h; a.xr = I(w.xr); a.xi = I(w.xi); a.w_re = l.c_re_t; a.w_im = l.c_im_t; a.D = l.D;
-            a.x1 = I(w.x1); a.tr_ys = tr ? tr->ys : nullptr; a.N = N; a.H = H; a.P = P; a.mw = mw_for(H);
+            a.bn = bn; a.x = h; a.xs = I(w.xs); a.w_re = l.c_re_t; a.w_im = l.c_im_t; a.D = l.D;
+            a.x1 = I(w.x1); a.tr_ys = tr ? tr->ys : nullptr; a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
+            a.mw = mw_for(H);
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
-            a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits;
-            if (l.c24) S5_DISPATCH_MW_C(a.mw, true, tiles, st, a);
-            else hipMemsetAsync(&d->wide, 0xff, 4, st); // no 24-bit variant: force the 32-bit kernel
-            S5_DISPATCH_MW_C(a.mw, false, tiles, st, a);
+            a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.xmax = xmax; a.dynw = d; a.status = status;
+            const bool c24 = l.c24 && !(m->flags & S5FXP_MODEL_FORCE_GENERIC);
+            if (c24) S5_DISPATCH_MW_C(a.mw, true, 0, tiles, st, a);
+            else hipMemsetAsync(&d->redo, 0xff, 4, st); // no 24-bit variant: the exact pass does all the work
+            if (quad) {
+                sl.run_if = &d->redo;
+                hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+            }
+            S5_DISPATCH_MW_C(a.mw, false, 1, tiles, st, a);
+            if (tr && (tr->xs_re || tr->xs_im))
+                hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I(w.xs),
+                                   tr->xs_re, tr->xs_im, B, L, P, w.TB);
         }
         // ---- out2 + sigmoid + gate + residual maxima
         {

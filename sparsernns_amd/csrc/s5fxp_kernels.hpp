@@ -6,6 +6,7 @@
 // (paths into /root/reference/sparseRNNs/).
 #pragma once
 #include "fxp_prims.hpp"
+#include "scan_quad.hpp"
 
 namespace s5 {
 using namespace fxp;
@@ -28,7 +29,7 @@ struct LayerDyn {
     int32_t pad0;
     AddCb res;         // gate + skip                    fxpmodel.py:1147-1152
     uint32_t mx[16];   // float32 maxima as bit patterns: [0..2] bn1, [3] bn2, [4] bn3, [5..7] bn4, [8..10] res
-    int32_t wide;      // 1 if a post-ReLU state does not fit 24 bits (C projection needs 32-bit multiplies)
+    int32_t redo;      // 1 if a state exceeded the fast kernels' exactness bound: the exact kernels re-run the layer
     int32_t pad1[3];
 };
 
@@ -332,11 +333,14 @@ struct BprojArgs {
     BnArgs bn;
     const int32_t *x; // (N,H) layer input
     const int32_t *w; // (H,2P)
-    int32_t *bu_re, *bu_im; // (N,P)
+    int32_t *bq;               // native stream: Bu shifted to the state exponent
+    int32_t *tr_bu_re, *tr_bu_im; // optional traces (N,P): Bu as the reference stores it
     int32_t *tr_pre_s5, *tr_u; // optional traces (N,H)
     int64_t N;
+    int32_t L, TB;
     int32_t H, P, mw;
     int32_t rs_re, rs_im, bre_bits, bim_bits;
+    int32_t sh_re, sh_im;      // Bu exponent - x exponent
 };
 
 template <int MWMAX, bool X24>
@@ -357,36 +361,56 @@ __global__ __launch_bounds__(256) void k_bproj(BprojArgs a)
     mm_accumulate<MWMAX, X24>(S, acc, loadx, a.w, a.H, 2 * a.P, a.mw, n0, a.N);
     mm_stage_out<MWMAX>(S.out, acc, a.mw);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int nl = wave; nl < TN; nl += 4) {
+    // epilogue in stream order [time block][state][re|im][step]: consecutive threads write consecutive words
+    const int per_blk = a.P * 8;
+    for (int idx = threadIdx.x; idx < (TN / 4) * per_blk; idx += 256) {
+        const int tbl = idx / per_blk, rem = idx - tbl * per_blk;
+        const int p = rem >> 3, c = (rem >> 2) & 1, j = rem & 3;
+        const int nl = tbl * 4 + j;
         const int64_t n = n0 + nl;
-        if (n >= a.N) break;
-        for (int m = lane; m < 2 * a.P; m += 64) {
-            const int32_t raw = S.out[nl][m];
-            if (m < a.P) a.bu_re[n * a.P + m] = sat(asr(raw, a.rs_re), a.bre_bits);
-            else a.bu_im[n * a.P + (m - a.P)] = sat(asr(raw, a.rs_im), a.bim_bits);
-        }
+        if (n >= a.N) continue;
+        const int32_t raw = S.out[nl][c * a.P + p];
+        // Bu = sat(asr(u@B, rs)) (fxparray.py:667-676), then the scan's shiftto (fxpmodel.py:158-167)
+        const int32_t bu = c ? sat(asr(raw, a.rs_im), a.bim_bits) : sat(asr(raw, a.rs_re), a.bre_bits);
+        const int sh = c ? a.sh_im : a.sh_re;
+        const int64_t b = n / a.L;
+        const int t = (int)(n - b * a.L);
+        a.bq[native_word(b, t, p, c, a.TB, a.P)] = sh > 0 ? asr(bu, sh) : wshl(bu, -sh);
+        if (c == 0 && a.tr_bu_re) a.tr_bu_re[n * a.P + p] = bu;
+        if (c == 1 && a.tr_bu_im) a.tr_bu_im[n * a.P + p] = bu;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// The sequential recurrence (fxpmodel.py:147-208): one lane per (sequence, state), Bu read
-// coalesced across the state axis and prefetched UNROLL steps ahead.
+// "Scan-native" stream layout shared by the B projection (writer), the recurrence kernels and the
+// C projection (reader); see scan_quad.hpp.  TB = time blocks of 4 steps per sequence (padded).
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// The sequential recurrence (fxpmodel.py:147-208), one lane per (sequence, state), 32-bit
+// multiplies: exact for every int32 input.  Used by the op-level s5fxp_scan (plain (B,L,P) layout)
+// and as the fallback of the model forward (native layout) when the fast kernel's range check fails.
 //   re' = asr(Ar*xr, eAr) - asr(Ai*xi, eAr) + shiftto(Bu_re)
 //   im' = asr(Ar*xi, eAi) + asr(Ai*xr, eAi) + shiftto(Bu_im)          no clip, int32 wrap.
 // ---------------------------------------------------------------------------------------------
 struct ScanArgs {
-    const int32_t *bu_re, *bu_im; // (B,L,P)
+    const int32_t *bu_re, *bu_im; // plain: (B,L,P) each.  native: bu_re = stream (already shifted), bu_im unused
     const int32_t *a_re, *a_im;   // (P)
-    int32_t *out_re, *out_im;     // (B,L,P): post-ReLU states if relu, raw otherwise
-    int32_t *raw_re, *raw_im;     // optional raw-state traces
-    int32_t B, L, P;
+    int32_t *out_re, *out_im;     // plain: (B,L,P) each (post-ReLU if relu).  native: out_re = stream of raw states
+    int32_t B, L, P, TB;
     int32_t ea_re, ea_im;
     int32_t sh_re, sh_im; // Bu exponent - x exponent: > 0 right shift, <= 0 left shift (fxpmodel.py:158-167)
     int32_t relu;
-    int32_t *wide; // set to 1 if a stored state does not fit 24 signed bits
-    int32_t *status;
+    const int32_t *run_if; // native fallback: run only when *run_if != 0 (nullptr: always)
 };
+
+__device__ __forceinline__ void scan_step(int32_t Ar, int32_t Ai, int ea_re, int ea_im, int32_t br, int32_t bi,
+                                          int32_t &xr, int32_t &xi)
+{
+    const int32_t rr = wadd(wsub(asr(wmul(Ar, xr), ea_re), asr(wmul(Ai, xi), ea_re)), br);
+    const int32_t ri = wadd(wadd(asr(wmul(Ar, xi), ea_im), asr(wmul(Ai, xr), ea_im)), bi);
+    xr = rr;
+    xi = ri;
+}
 
 template <int UNROLL>
 __global__ __launch_bounds__(64) void k_scan_lane(ScanArgs a)
@@ -398,89 +422,139 @@ __global__ __launch_bounds__(64) void k_scan_lane(ScanArgs a)
     const int b = (int)(g / a.P), p = (int)(g % a.P);
     const int64_t base = (int64_t)b * a.L * a.P + p;
     const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
-    int32_t xr = 0, xi = 0, wide = 0;
-    int32_t cr[UNROLL], ci[UNROLL], nr[UNROLL], ni[UNROLL];
+    int32_t xr = 0, xi = 0;
+    int32_t r0[UNROLL], i0[UNROLL], r1[UNROLL], i1[UNROLL];
     auto load = [&](int32_t (&r)[UNROLL], int32_t (&i)[UNROLL], int t0) {
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const int t = t0 + j;
-            const bool ok = t < a.L;
-            const int64_t off = base + (int64_t)(ok ? t : a.L - 1) * a.P;
+            const int64_t off = base + (int64_t)(t < a.L ? t : a.L - 1) * a.P;
             r[j] = a.bu_re[off];
             i[j] = a.bu_im[off];
         }
     };
-    load(cr, ci, 0);
-    for (int t0 = 0; t0 < a.L; t0 += UNROLL) {
-        if (t0 + UNROLL < a.L) load(nr, ni, t0 + UNROLL);
+    auto run = [&](const int32_t (&r)[UNROLL], const int32_t (&i)[UNROLL], int t0) {
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const int t = t0 + j;
             if (t < a.L) {
-                const int32_t br = a.sh_re > 0 ? asr(cr[j], a.sh_re) : wshl(cr[j], -a.sh_re);
-                const int32_t bi = a.sh_im > 0 ? asr(ci[j], a.sh_im) : wshl(ci[j], -a.sh_im);
-                const int32_t rr = wadd(wsub(asr(wmul(Ar, xr), a.ea_re), asr(wmul(Ai, xi), a.ea_re)), br);
-                const int32_t ri = wadd(wadd(asr(wmul(Ar, xi), a.ea_im), asr(wmul(Ai, xr), a.ea_im)), bi);
-                xr = rr;
-                xi = ri;
-                const int64_t off = base + (int64_t)t * a.P;
+                const int32_t br = a.sh_re > 0 ? asr(r[j], a.sh_re) : wshl(r[j], -a.sh_re);
+                const int32_t bi = a.sh_im > 0 ? asr(i[j], a.sh_im) : wshl(i[j], -a.sh_im);
+                scan_step(Ar, Ai, a.ea_re, a.ea_im, br, bi, xr, xi);
                 if (active) {
-                    if (a.raw_re) a.raw_re[off] = xr;
-                    if (a.raw_im) a.raw_im[off] = xi;
                     int32_t sr = xr, si = xi;
                     if (a.relu) crelu(sr, si);
-                    wide |= (sr ^ (sr >> 31)) | (si ^ (si >> 31));
+                    const int64_t off = base + (int64_t)t * a.P;
                     a.out_re[off] = sr;
                     a.out_im[off] = si;
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
-            cr[j] = nr[j];
-            ci[j] = ni[j];
-        }
+    };
+    // two register sets alternate, so a prefetched chunk is never copied (a copy would force vmcnt(0))
+    load(r0, i0, 0);
+    for (int t0 = 0; t0 < a.L; t0 += 2 * UNROLL) {
+        load(r1, i1, t0 + UNROLL);
+        run(r0, i0, t0);
+        load(r0, i0, t0 + 2 * UNROLL);
+        run(r1, i1, t0 + UNROLL);
     }
-    if (a.wide && __any(wide >> 23) && threadIdx.x == 0) {
-        atomicExch(a.wide, 1);
-        if (a.status) atomicOr(a.status, ST_WIDE_STATE);
+}
+
+// native-layout variant: 4 steps per 16-byte access
+__global__ __launch_bounds__(64) void k_scan_lane_native(ScanArgs a)
+{
+    if (a.run_if && *a.run_if == 0) return;
+    const int64_t gid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t total = (int64_t)a.B * a.P;
+    if (gid >= total) return;
+    const int b = (int)(gid / a.P), p = (int)(gid % a.P);
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int nblk = (a.L + 3) >> 2;
+    int32_t xr = 0, xi = 0;
+    for (int tb = 0; tb < nblk; ++tb) {
+        const int64_t w = native_word(b, tb << 2, p, 0, a.TB, a.P);
+        const int4 vr = *reinterpret_cast<const int4 *>(a.bu_re + w);
+        const int4 vi = *reinterpret_cast<const int4 *>(a.bu_re + w + 4);
+        int4 orr, oi;
+        scan_step(Ar, Ai, a.ea_re, a.ea_im, vr.x, vi.x, xr, xi); orr.x = xr; oi.x = xi;
+        scan_step(Ar, Ai, a.ea_re, a.ea_im, vr.y, vi.y, xr, xi); orr.y = xr; oi.y = xi;
+        scan_step(Ar, Ai, a.ea_re, a.ea_im, vr.z, vi.z, xr, xi); orr.z = xr; oi.z = xi;
+        scan_step(Ar, Ai, a.ea_re, a.ea_im, vr.w, vi.w, xr, xi); orr.w = xr; oi.w = xi;
+        *reinterpret_cast<int4 *>(a.out_re + w) = orr;
+        *reinterpret_cast<int4 *>(a.out_re + w + 4) = oi;
+    }
+}
+
+// native stream -> plain (B,L,P) pair (traces only)
+__global__ void k_unpack_native(const int32_t *__restrict__ stream, int32_t *__restrict__ re, int32_t *__restrict__ im,
+                                int B, int L, int P, int TB)
+{
+    const int64_t n = (int64_t)B * L * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int64_t bt = i / P;
+        const int t = (int)(bt % L);
+        const int64_t b = bt / L;
+        const int64_t w = native_word(b, t, p, 0, TB, P);
+        if (re) re[i] = stream[w];
+        if (im) im[i] = stream[w + 4];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // C projection + feed-through (fxpmodel.py:746-793) + ReLU (fxpmodel.py:1125):
 //   cx = sat(sat(asr(xr@C_re^T)) - sat(asr(xi@C_im^T))); y = sat(2*cx + sat(asr(D*u)))
-// W_re / W_im are (P,H) = C_re^T / C_im^T.  u is recomputed from the layer input.
-// Launched twice (X24 and 32-bit); the LayerDyn::wide flag picks the one that does the work.
+// Reads the RAW states from the native stream and applies the complex ReLU (fxpmodel.py:740-742)
+// while loading.  W_re / W_im are (P,H) = C_re^T / C_im^T.  u is recomputed from the layer input.
+// PASS 0 (fast): also range-checks every raw state against xmax (the exactness bound of the
+//   recurrence kernel that produced it, and < 2^23 so the 24-bit multiplies here are exact); a
+//   violation sets LayerDyn::redo.  PASS 1 (exact): runs only when redo is set, 32-bit multiplies.
 // ---------------------------------------------------------------------------------------------
 struct CprojArgs {
     BnArgs bn;
     const int32_t *x;          // (N,H) layer input (for u)
-    const int32_t *xr, *xi;    // (N,P) post-ReLU states
+    const int32_t *xs;         // native stream of raw states
     const int32_t *w_re, *w_im; // (P,H)
     const int32_t *D;          // (H)
     int32_t *x1;               // (N,H) relu(ys)
     int32_t *tr_ys;            // optional (N,H)
     int64_t N;
+    int32_t L, TB;
     int32_t H, P, mw;
     int32_t rs_re, rs_im, rs_d, y_bits;
+    int32_t xmax;
+    LayerDyn *dynw;
+    int32_t *status;
 };
 
-template <int MWMAX, bool X24>
+template <int MWMAX, bool X24, int PASS>
 __global__ __launch_bounds__(256) void k_cproj(CprojArgs a)
 {
     __shared__ MMShared<MWMAX> S;
     __shared__ int32_t out_re[TN][4 * MWMAX + 1];
     const LayerDyn d = *a.bn.dyn;
-    if ((d.wide != 0) == X24) return; // the other instantiation handles this forward
+    if (PASS == 1 && d.redo == 0) return;
     const int64_t n0 = (int64_t)blockIdx.x * TN;
     int32_t acc[MWMAX];
-    mm_accumulate<MWMAX, X24>(S, acc, [&](int64_t n, int k) { return a.xr[n * a.P + k]; }, a.w_re, a.P, a.H, a.mw, n0,
-                              a.N);
+    bool bad = false;
+    auto load_c = [&](int64_t n, int k, int c) {
+        const int64_t b = n / a.L;
+        const int t = (int)(n - b * a.L);
+        const int64_t w = native_word(b, t, k, 0, a.TB, a.P);
+        int32_t re = a.xs[w], im = a.xs[w + 4];
+        if (PASS == 0) bad |= (re > a.xmax) | (re < -a.xmax) | (im > a.xmax) | (im < -a.xmax);
+        crelu(re, im);
+        return c ? im : re;
+    };
+    mm_accumulate<MWMAX, X24>(S, acc, [&](int64_t n, int k) { return load_c(n, k, 0); }, a.w_re, a.P, a.H, a.mw, n0, a.N);
     mm_stage_out<MWMAX>(out_re, acc, a.mw);
-    mm_accumulate<MWMAX, X24>(S, acc, [&](int64_t n, int k) { return a.xi[n * a.P + k]; }, a.w_im, a.P, a.H, a.mw, n0,
-                              a.N);
+    mm_accumulate<MWMAX, X24>(S, acc, [&](int64_t n, int k) { return load_c(n, k, 1); }, a.w_im, a.P, a.H, a.mw, n0, a.N);
     mm_stage_out<MWMAX>(S.out, acc, a.mw);
+    if (PASS == 0 && __any(bad) && (threadIdx.x & 63) == 0) {
+        atomicExch(&a.dynw->redo, 1);
+        atomicOr(a.status, ST_WIDE_STATE);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int nl = wave; nl < TN; nl += 4) {

@@ -1,0 +1,163 @@
+// scan_quad.hpp -- the exact sequential diagonal-SSM recurrence at 3 dependent VALU ops per step.
+//
+// Reference step (sparseRNNs/fxpmodel.py:155-169), per state, int32 with wrap, no clip:
+//     re' = asr(Ar*xr, e_re) - asr(Ai*xi, e_re) + bre          im' = asr(Ar*xi, e_im) + asr(Ai*xr, e_im) + bim
+// The recurrence is latency bound (L sequential steps, only B*P independent chains), so the kernel
+// minimises the dependent chain, not the instruction count.  Four lanes (a quad) carry one state:
+//
+//   z  = c * x + k          v_mad_i32_i24   c = +-A * 2^(16-e)  (so the floor shift becomes ">> 16"),
+//                                           k = 2^16 - 2^(16-e) on the lane that must deliver -floor(.)
+//   q  = (z >> 16) + b      v_add_u32 SDWA  src0 = sign-extended high half of z; b = Bu on one lane of
+//                                           each partner pair, 0 on the other
+//   x' = q + q[partner]     v_add_u32 DPP   quad_perm; afterwards BOTH partners hold the new component
+//
+// Which lanes are partners alternates every step (phase A / phase B) so that every lane already holds
+// the component its next multiply needs -- no cross-lane move in front of the multiply:
+//   phase A: lanes {0,3} hold re, {1,2} hold im;  pairs (0,2)->re', (1,3)->im';  quad_perm [2,3,0,1]
+//   phase B: lanes {0,2} hold re, {1,3} hold im;  pairs (0,3)->re', (1,2)->im';  quad_perm [3,2,1,0]
+// Lane 0 always ends a step holding re', lane 1 im'.
+//
+// Exactness: with |c*x| + k < 2^31 the 24-bit multiply-add is the true integer, its ">>16" equals
+// asr(A*x, e) (or its exact negation), and all additions wrap like int32.  The bound is
+// |x| <= xmax = (2^31 - 1 - 2^16) / max|c|  (32767 for 16-bit Lambda at exponent 15, i.e. the state's
+// nominal width).  The consumer of the states checks |x| <= xmax on every stored state; by
+// induction over t that proves every product was exact.  If the check fails the forward re-runs the
+// layer with the 32-bit one-lane-per-state kernel (k_scan_lane), so results are exact either way.
+//
+// Streams use the "scan-native" layout, written by the B projection and read by the C projection:
+//     word(b, tb, p, c, j) = ((((b*TB + tb)*P + p)*2 + c)*4 + j),   t = 4*tb + j,  c: 0 = re, 1 = im
+// so lanes 0/1 of a quad move 16-byte vectors of four consecutive steps and a wave (16 states) reads
+// and writes 512 contiguous bytes per 4 steps.  Lanes 2/3 use an out-of-range buffer offset: their
+// loads return 0 and their stores are dropped by the buffer range check.
+#pragma once
+#include "fxp_prims.hpp"
+
+namespace s5 {
+
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+
+// word index of (sequence b, step t, state p, component c) in a scan-native stream with TB blocks/sequence
+__device__ __forceinline__ int64_t native_word(int64_t b, int t, int p, int c, int TB, int P)
+{
+    return ((((b * TB + (t >> 2)) * P + p) * 2 + c) << 2) + (t & 3);
+}
+
+struct ScanQuadArgs {
+    const int32_t *bq;          // native stream: Bu already shifted to the state exponent
+    int32_t *xs;                // native stream: raw states
+    const int32_t *a_re, *a_im; // (P)
+    int32_t B, TB, P;           // TB = number of 4-step time blocks per sequence (stream extent)
+    int32_t ea_re, ea_im;
+};
+
+// PRE is "s_nop 1\n\t" for the first step after a 16-byte buffer_store: gfx940+ needs 2 wait states
+// between such a store and a VALU write to one of its data registers, and hipcc pads nothing
+// around inline asm.
+#define S5_SCAN_STEP(PRE, PERM, XIN, XOUT, C, K, BQ)                                                           \
+    asm volatile(PRE "v_mad_i32_i24 %0, %2, %3, %4\n\t"                                                          \
+                 "v_add_u32_sdwa %0, sext(%0), %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 "        \
+                 "src1_sel:DWORD\n\t"                                                                          \
+                 "s_nop 1\n\t"                                                                                 \
+                 "v_add_u32_dpp %1, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"                  \
+                 : "=&v"(tmp), "=v"(XOUT)                                                                      \
+                 : "v"(C), "v"(XIN), "v"(K), "v"(BQ))
+
+// One wave = 16 states of one sequence.  DEPTH = time blocks (of 4 steps) kept in flight.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_scan_quad(ScanQuadArgs a)
+{
+    const int lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    // wave-uniform by construction; readfirstlane lets the compiler keep the descriptors in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave_in_block);
+    const int groups = a.P >> 4; // waves per sequence
+    const int b = wave / groups, p0 = (wave % groups) << 4;
+    if (b >= a.B) return;
+    const int s = lane >> 2, r = lane & 3;
+    const int p = p0 + s;
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int sre = 16 - a.ea_re, sim = 16 - a.ea_im;
+    const int32_t kre = (1 << 16) - (1 << sre);
+    // phase A: l0 (Ar->re) l1 (Ar->im) l2 (-Ai->re, k) l3 (Ai->im);  phase B: l2 (Ai->im), l3 (-Ai->re, k)
+    int32_t cA, cB, kA = 0, kB = 0;
+    if (r == 0) { cA = cB = Ar << sre; }
+    else if (r == 1) { cA = cB = Ar << sim; }
+    else if (r == 2) { cA = -(Ai << sre); kA = kre; cB = Ai << sim; }
+    else { cA = Ai << sim; cB = -(Ai << sre); kB = kre; }
+
+    // per-wave buffer descriptors: base = first word of (b, tb=0, p0); lanes 2,3 are out of range
+    const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // words
+    const unsigned blk_stride = (unsigned)a.P * 32u;              // bytes per time block
+    const unsigned extent = (unsigned)a.TB * blk_stride;
+    auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.bq) + wave_off, 0, extent, 0x00020000);
+    auto rout = __builtin_amdgcn_make_buffer_rsrc(a.xs + wave_off, 0, extent, 0x00020000);
+    const unsigned voff = r < 2 ? (unsigned)(s * 32 + r * 16) : 0xFFFFFF00u;
+
+    u32x4 ring[DEPTH];
+    unsigned soff_ld = 0, soff_st = 0;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+        ring[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voff, soff_ld, 0);
+        soff_ld += blk_stride; // the stream is padded to a multiple of DEPTH blocks
+    }
+    int32_t x = 0, tmp;
+    for (int tb0 = 0; tb0 < a.TB; tb0 += DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            const u32x4 cur = ring[i];
+            int32_t x1, x2, x3, x4;
+            S5_SCAN_STEP("s_nop 1\n\t", "[2,3,0,1]", x, x1, cA, kA, cur[0]);
+            S5_SCAN_STEP("", "[3,2,1,0]", x1, x2, cB, kB, cur[1]);
+            S5_SCAN_STEP("", "[2,3,0,1]", x2, x3, cA, kA, cur[2]);
+            S5_SCAN_STEP("", "[3,2,1,0]", x3, x4, cB, kB, cur[3]);
+            x = x4;
+            // refill this ring slot (clamped at the end of the stream; the extra data is never used)
+            ring[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voff, soff_ld < extent ? soff_ld : extent - blk_stride, 0);
+            soff_ld += blk_stride;
+            u32x4 o;
+            o[0] = (unsigned)x1; o[1] = (unsigned)x2; o[2] = (unsigned)x3; o[3] = (unsigned)x4;
+            __builtin_amdgcn_raw_buffer_store_b128(o, rout, voff, soff_st, 0);
+            soff_st += blk_stride;
+        }
+    }
+}
+
+#include "scan_quad_asm.inc"
+
+// Hand-scheduled variant: the two wait states in front of every DPP add are filled with the loop's own
+// buffer_load / buffer_store / s_add instructions (tools/gen_scan_asm.py).  Same algorithm, layout and
+// exactness bound as k_scan_quad.  One wave per workgroup: every wave gets its own CU front end.
+// The stream must be followed by S5_SCAN_ASM_DEPTH blocks of readable padding (the ring runs ahead).
+__global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int groups = a.P >> 4;
+    const int b = wave / groups, p0 = (wave % groups) << 4;
+    if (b >= a.B) return;
+    const int s = lane >> 2, r = lane & 3;
+    const int p = p0 + s;
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int sre = 16 - a.ea_re, sim = 16 - a.ea_im;
+    const int32_t kre = (1 << 16) - (1 << sre);
+    int32_t cA, cB, kA = 0, kB = 0;
+    if (r == 0) { cA = cB = Ar << sre; }
+    else if (r == 1) { cA = cB = Ar << sim; }
+    else if (r == 2) { cA = -(Ai << sre); kA = kre; cB = Ai << sim; }
+    else { cA = Ai << sim; cB = -(Ai << sre); kB = kre; }
+    const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // words
+    const unsigned blk_stride = (unsigned)a.P * 32u;
+    const unsigned extent = (unsigned)a.TB * blk_stride;
+    const unsigned long long bin = (unsigned long long)(a.bq + wave_off), bout = (unsigned long long)(a.xs + wave_off);
+    u32x4 rin, rout;
+    rin[0] = (unsigned)bin; rin[1] = (unsigned)(bin >> 32) & 0xffffu; rin[2] = extent; rin[3] = 0x00020000u;
+    rout[0] = (unsigned)bout; rout[1] = (unsigned)(bout >> 32) & 0xffffu; rout[2] = extent; rout[3] = 0x00020000u;
+    const unsigned voff = r < 2 ? (unsigned)(s * 32 + r * 16) : 0xFFFFFF00u;
+    unsigned sld = 0, sst = 0, cnt = (unsigned)a.TB / S5_SCAN_ASM_DEPTH;
+    asm volatile(S5_SCAN_ASM_BODY
+                 : [sld] "+s"(sld), [sst] "+s"(sst), [cnt] "+s"(cnt)
+                 : [ca] "v"(cA), [cb] "v"(cB), [ka] "v"(kA), [kb] "v"(kB), [voff] "v"(voff), [rin] "s"(rin),
+                   [rout] "s"(rout), [stride] "s"(blk_stride)
+                 : S5_SCAN_ASM_CLOBBERS);
+}
+
+} // namespace s5

@@ -123,7 +123,8 @@ class Engine:
         return self._ws
 
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
-                traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None) -> None:
+                traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
+                scan_events: Optional[list] = None) -> None:
         """Launches one forward on the current stream; nothing is synchronised."""
         ws = self.workspace(B, L)
         tr = None
@@ -133,6 +134,7 @@ class Engine:
                 for k in TRACE_FIELDS:
                     if k in d:
                         setattr(tr[i], k, d[k].data_ptr())
+        opts = _lib.ForwardOpts()
         if allreduce is not None:
             def _cb(ctx, dev_ptr, n, stream):  # noqa: ANN001
                 try:
@@ -142,13 +144,16 @@ class Engine:
                     import traceback
                     traceback.print_exc()
                     return 1
-            cb = _lib.ALLREDUCE_FN(_cb)
-            self._cb_keep = cb
-        else:
-            cb = C.cast(None, _lib.ALLREDUCE_FN)
+            opts.allreduce = _lib.ALLREDUCE_FN(_cb)
+        if scan_events is not None:
+            assert len(scan_events) == 2 * self.n_layers
+            arr = (C.c_void_p * len(scan_events))(*[e.cuda_event for e in scan_events])
+            opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
+            self._ev_keep = arr
+        self._cb_keep = opts
         check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
                                       ws.numel(), self.status.data_ptr(),
-                                      C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, cb, None,
+                                      C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, C.byref(opts),
                                       torch.cuda.current_stream().cuda_stream), "s5fxp_model_forward")
 
     def check_status(self) -> np.ndarray:
