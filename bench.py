@@ -39,6 +39,7 @@ def main() -> None:
     ap.add_argument("--dim-scale", type=float, default=0.5)
     ap.add_argument("--sparsity", type=float, default=0.0)
     ap.add_argument("--quantization", default="w8a16")
+    ap.add_argument("--state-headroom-bits", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="sequences in the bounded CPU-baseline sample")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
@@ -70,7 +71,9 @@ def main() -> None:
     dev = torch.device("cuda", torch.cuda.current_device())
 
     B, L = args.batch, args.seq_len
-    md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity)
+    # one extra integer bit for the (never clipped) SSM state: see synth.make_model(state_headroom_bits)
+    md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity,
+                                    calib_L=1024, state_headroom_bits=args.state_headroom_bits)
     allreduce = None
     if args.global_exponents and world > 1:
         from sparsernns_amd.dist import make_exponent_allreduce

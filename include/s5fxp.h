@@ -211,6 +211,9 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
 /* Static facts about a created model (for INTEGRATION / debugging). */
 int s5fxp_model_out_exp(const s5fxp_model *m);
 int s5fxp_model_out_bits(const s5fxp_model *m);
+/* 1 if the int8-MFMA kernels were packed for this model (NDNS shapes, <= 8-bit weights, <= 16-bit
+ * activations); the forward uses them whenever L % 4 == 0 and falls back to the generic kernels otherwise. */
+int s5fxp_model_is_fast(const s5fxp_model *m);
 
 #ifdef __cplusplus
 }

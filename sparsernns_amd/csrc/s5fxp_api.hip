@@ -4,6 +4,7 @@
 // caller's stream.  No device allocation, no synchronisation, no global mutable state.
 #include "../../include/s5fxp.h"
 #include "s5fxp_kernels.hpp"
+#include "mfma_proj.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -43,14 +44,14 @@ constexpr int MW_LIMIT = 68;
     } while (0)
 
 // k_cproj keeps two output tiles in LDS; its column budget stops at 48 (H <= 192)
-#define S5_DISPATCH_MW_C(mw, X24, PASS, grid, stream, args)                                                         \
+#define S5_DISPATCH_MW_C(mw, X24, PASS, AT, grid, stream, args)                                                         \
     do {                                                                                                      \
-        if ((mw) <= 4) hipLaunchKernelGGL((k_cproj<4, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);         \
-        else if ((mw) <= 8) hipLaunchKernelGGL((k_cproj<8, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);    \
-        else if ((mw) <= 16) hipLaunchKernelGGL((k_cproj<16, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
-        else if ((mw) <= 24) hipLaunchKernelGGL((k_cproj<24, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
-        else if ((mw) <= 32) hipLaunchKernelGGL((k_cproj<32, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);  \
-        else hipLaunchKernelGGL((k_cproj<48, X24, PASS>), dim3(grid), dim3(256), 0, stream, args);                  \
+        if ((mw) <= 4) hipLaunchKernelGGL((k_cproj<4, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);         \
+        else if ((mw) <= 8) hipLaunchKernelGGL((k_cproj<8, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);    \
+        else if ((mw) <= 16) hipLaunchKernelGGL((k_cproj<16, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);  \
+        else if ((mw) <= 24) hipLaunchKernelGGL((k_cproj<24, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);  \
+        else if ((mw) <= 32) hipLaunchKernelGGL((k_cproj<32, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);  \
+        else hipLaunchKernelGGL((k_cproj<48, X24, PASS, AT>), dim3(grid), dim3(256), 0, stream, args);                  \
     } while (0)
 constexpr int MW_LIMIT_C = 48;
 
@@ -259,11 +260,14 @@ struct LayerDev {
     int32_t lut[8];
 };
 
+struct FastModel; // int8-MFMA path (s5fxp_fast.hpp); nullptr when the model is not eligible
+
 struct s5fxp_model {
     int n_layers = 0, d_in = 0, H = 0, P = 0, d_out = 0;
     DenseDev enc, dec;
     std::vector<LayerDev> layers;
     int flags = 0;
+    FastModel *fast = nullptr;
 };
 
 namespace {
@@ -373,6 +377,15 @@ int validate(const s5fxp_model_desc *d)
     return S5FXP_OK;
 }
 
+constexpr int SCAN_DEPTH = S5_SCAN_ASM_DEPTH; // time blocks (4 steps each) the quad recurrence kernel keeps in flight
+
+} // namespace
+
+#include "s5fxp_fast.hpp"
+
+namespace {
+
+// m == nullptr: size pass (an upper bound: it includes the MFMA-path tensors whenever the model is eligible)
 size_t pack_all(const s5fxp_model_desc *d, Packer &p, s5fxp_model *m, bool allow24)
 {
     DenseDev tmp_e, tmp_d;
@@ -382,6 +395,10 @@ size_t pack_all(const s5fxp_model_desc *d, Packer &p, s5fxp_model *m, bool allow
         pack_layer(p, d->layers[i], m ? m->layers[i] : tmp, allow24);
     }
     pack_dense(p, d->decoder, m ? m->dec : tmp_d, allow24);
+    if ((allow24 || !m) && fast_eligible(d)) {
+        if (m) m->fast = new FastModel();
+        pack_fast(p, d, m ? m->fast : nullptr);
+    }
     return p.off;
 }
 
@@ -432,12 +449,17 @@ extern "C" int s5fxp_model_create(const s5fxp_model_desc *desc, void *dev_blob, 
     return S5FXP_OK;
 }
 
-extern "C" void s5fxp_model_destroy(s5fxp_model *m) { delete m; }
+extern "C" void s5fxp_model_destroy(s5fxp_model *m)
+{
+    if (m) delete m->fast;
+    delete m;
+}
 extern "C" int s5fxp_model_out_exp(const s5fxp_model *m) { return m ? m->dec.out_exp : 0; }
 extern "C" int s5fxp_model_out_bits(const s5fxp_model *m) { return m ? m->dec.out_bits : 0; }
+/* 1 if the int8-MFMA path was packed for this model (it also needs L % 4 == 0 at run time) */
+extern "C" int s5fxp_model_is_fast(const s5fxp_model *m) { return m && m->fast ? 1 : 0; }
 
 namespace {
-constexpr int SCAN_DEPTH = S5_SCAN_ASM_DEPTH; // time blocks (4 steps each) the quad recurrence kernel keeps in flight
 
 struct WsLayout {
     size_t hA, hB, bq, xs, x1, z, dyn, total;
@@ -468,7 +490,9 @@ WsLayout ws_layout(const s5fxp_model *m, int B, int L)
 extern "C" size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L)
 {
     if (!m || B < 1 || L < 1) return 0;
-    return ws_layout(m, B, L).total;
+    const size_t g = ws_layout(m, B, L).total;
+    const size_t f = m->fast ? fast_ws(m, B, L).total : 0;
+    return g > f ? g : f;
 }
 
 extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L,
@@ -476,6 +500,9 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
                                    const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, void *stream)
 {
     if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
+    if (workspace_bytes < s5fxp_workspace_bytes(m, B, L)) return S5FXP_EWORKSPACE;
+    if (m->fast && (L % 4) == 0 && (int64_t)B * L * m->d_in * 4 < 0xfffffff0ll)
+        return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
@@ -591,13 +618,13 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
             a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.xmax = xmax; a.dynw = d; a.status = status;
             const bool c24 = l.c24 && !(m->flags & S5FXP_MODEL_FORCE_GENERIC);
-            if (c24) S5_DISPATCH_MW_C(a.mw, true, 0, tiles, st, a);
+            if (c24) S5_DISPATCH_MW_C(a.mw, true, 0, int32_t, tiles, st, a);
             else hipMemsetAsync(&d->redo, 0xff, 4, st); // no 24-bit variant: the exact pass does all the work
             if (quad) {
                 sl.run_if = &d->redo;
                 hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
             }
-            S5_DISPATCH_MW_C(a.mw, false, 1, tiles, st, a);
+            S5_DISPATCH_MW_C(a.mw, false, 1, int32_t, tiles, st, a);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);

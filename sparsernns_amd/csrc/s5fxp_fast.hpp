@@ -1,0 +1,344 @@
+// s5fxp_fast.hpp -- host side of the int8-MFMA forward (included by s5fxp_api.hip after Packer,
+// s5fxp_model, WsLayout-independent helpers).  Packs the weights for mfma_proj.hpp and enqueues the
+// w8a16 fast path:  encoder -> [BN maxima -> B proj -> recurrence -> C proj -> out2/gate -> residual] x L
+// -> decoder, with int16 activations and int32 recurrence streams.
+#pragma once
+
+struct MfmaWDev {
+    MfmaW w{};
+    const int32_t *bias_eff = nullptr; // [Np], bias moved to out_exp (dense layers only)
+};
+
+struct FastLayer {
+    MfmaWDev bproj, cre, cim, out2;
+    const int32_t *Dpad = nullptr; // [Np]
+};
+
+struct FastModel {
+    MfmaWDev enc, dec;
+    std::vector<FastLayer> layers;
+};
+
+namespace {
+
+inline const void *put_raw(Packer &p, const void *src, size_t bytes)
+{
+    const void *d = p.dev + p.off;
+    if (p.host) std::memcpy(p.host + p.off, src, bytes);
+    p.off = (p.off + bytes + 255) & ~(size_t)255;
+    return d;
+}
+
+inline bool fits_bits(const int32_t *v, size_t n, int bits)
+{
+    const int32_t hi = (1 << (bits - 1)) - 1, lo = -hi - 1;
+    for (size_t i = 0; i < n; ++i)
+        if (v[i] < lo || v[i] > hi) return false;
+    return true;
+}
+
+// The MFMA path is instantiated for the NDNS shapes (recipes/ndns.json at dim_scale 0.5 and 1.0) with
+// <= 8-bit weights and <= 16-bit activations; everything else runs the generic kernels.
+bool fast_eligible(const s5fxp_model_desc *d)
+{
+    if (d->n_layers < 1) return false;
+    const int H = d->encoder.M, K = d->encoder.K, M = d->decoder.M, P = d->layers[0].ssm.P;
+    if (!((H == 96 && P == 64) || (H == 192 && P == 128))) return false;
+    if (K <= 256 || K > 288 || M > 288 || M < 1) return false;
+    auto dense16 = [](const s5fxp_dense_desc &e) { return e.inp_bits <= 16 && e.out_bits <= 16 && e.b_bits <= 32; };
+    if (!dense16(d->encoder) || d->decoder.inp_bits > 16 || d->decoder.out_bits > 32) return false;
+    if (!fits_bits(d->encoder.weight, (size_t)K * H, 8) || !fits_bits(d->decoder.weight, (size_t)H * M, 8)) return false;
+    for (int i = 0; i < d->n_layers; ++i) {
+        const s5fxp_layer_desc &l = d->layers[i];
+        const s5fxp_ssm_desc &s = l.ssm;
+        if (s.P != P) return false;
+        const s5fxp_norm_desc &n = l.norm;
+        if (n.mean_bits > 16 || n.invsq_var_bits > 16 || (n.scale && n.scale_bits > 16) || (n.bias && n.bias_bits > 16))
+            return false;
+        if (s.u_bits > 16 || s.y_bits > 16 || s.Bu_re_bits > 32 || s.Bu_im_bits > 32) return false;
+        if (!dense16(l.out2) || l.l_bits > 16 || l.r_bits > 16 || l.res_bits > 16) return false;
+        if (!fits_bits(s.B_re, (size_t)P * H, 8) || !fits_bits(s.B_im, (size_t)P * H, 8) ||
+            !fits_bits(s.C_re, (size_t)H * P, 8) || !fits_bits(s.C_im, (size_t)H * P, 8) ||
+            !fits_bits(l.out2.weight, (size_t)H * H, 8))
+            return false;
+    }
+    return true;
+}
+
+// get(k, ch) -> weight; result rows are channels, padded and strided for conflict-free 16-byte LDS reads
+template <class Get>
+void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o)
+{
+    const int Kpad = (K + 31) / 32 * 32;
+    const int Kp = ((Kpad / 16) % 2 == 0) ? Kpad + 16 : Kpad;
+    const int Np = (M + 31) / 32 * 32;
+    std::vector<int8_t> wt((size_t)Np * Kp, 0);
+    std::vector<int32_t> cs(Np, 0);
+    for (int ch = 0; ch < M; ++ch) {
+        uint32_t sum = 0;
+        for (int k = 0; k < K; ++k) {
+            const int32_t v = get(k, ch);
+            wt[(size_t)ch * Kp + k] = (int8_t)v;
+            sum += (uint32_t)v;
+        }
+        cs[ch] = (int32_t)(sum * 128u);
+    }
+    o.w.wt = reinterpret_cast<const int8_t *>(put_raw(p, wt.data(), wt.size()));
+    o.w.cs128 = reinterpret_cast<const int32_t *>(put_raw(p, cs.data(), cs.size() * 4));
+    o.w.Kp = Kp;
+    o.w.Np = Np;
+}
+
+void pack_bias_eff(Packer &p, const s5fxp_dense_desc &e, int Np, MfmaWDev &o)
+{
+    std::vector<int32_t> b(Np, 0);
+    for (int ch = 0; ch < e.M; ++ch) b[ch] = fxp::chexp(e.bias[ch], e.b_bits, e.b_exp, e.out_exp);
+    o.bias_eff = reinterpret_cast<const int32_t *>(put_raw(p, b.data(), b.size() * 4));
+}
+
+void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
+{
+    FastModel tmp;
+    if (!f) f = &tmp;
+    f->layers.resize(d->n_layers);
+    const s5fxp_dense_desc &e = d->encoder;
+    pack_mfma(p, [&](int k, int ch) { return e.weight[(size_t)k * e.M + ch]; }, e.K, e.M, f->enc);
+    pack_bias_eff(p, e, f->enc.w.Np, f->enc);
+    for (int i = 0; i < d->n_layers; ++i) {
+        const s5fxp_layer_desc &l = d->layers[i];
+        const s5fxp_ssm_desc &s = l.ssm;
+        FastLayer &o = f->layers[i];
+        const int H = s.H, P = s.P;
+        pack_mfma(p, [&](int k, int ch) { return ch < P ? s.B_re[(size_t)ch * H + k] : s.B_im[(size_t)(ch - P) * H + k]; }, H,
+                  2 * P, o.bproj);
+        pack_mfma(p, [&](int k, int ch) { return s.C_re[(size_t)ch * P + k]; }, P, H, o.cre);
+        pack_mfma(p, [&](int k, int ch) { return s.C_im[(size_t)ch * P + k]; }, P, H, o.cim);
+        pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2);
+        pack_bias_eff(p, l.out2, o.out2.w.Np, o.out2);
+        std::vector<int32_t> Dp(o.cre.w.Np, 0);
+        for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
+        o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
+    }
+    const s5fxp_dense_desc &dd = d->decoder;
+    pack_mfma(p, [&](int k, int ch) { return dd.weight[(size_t)k * dd.M + ch]; }, dd.K, dd.M, f->dec);
+    pack_bias_eff(p, dd, f->dec.w.Np, f->dec);
+}
+
+struct FastWs {
+    size_t hA, hB, x1, z, bq, xs, dyn, total;
+    int TB;
+};
+
+FastWs fast_ws(const s5fxp_model *m, int B, int L)
+{
+    const size_t N = (size_t)B * L;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    FastWs w{};
+    w.TB = ((L + 3) / 4 + SCAN_DEPTH - 1) / SCAN_DEPTH * SCAN_DEPTH;
+    size_t off = 0;
+    const size_t nh = al(N * m->H * 2 + 64); // int16 (+ slack for the 32-byte fragment loads of clamped tail lanes)
+    const size_t ns = al(((size_t)B * w.TB + SCAN_DEPTH) * m->P * 8 * 4);
+    w.hA = off; off += nh;
+    w.hB = off; off += nh;
+    w.x1 = off; off += nh;
+    w.z = off; off += nh;
+    w.bq = off; off += ns;
+    w.xs = off; off += ns;
+    w.dyn = off; off += al(sizeof(LayerDyn) * (size_t)m->n_layers);
+    w.total = off;
+    return w;
+}
+
+template <class K, class A>
+inline void launch_smem(K kernel, unsigned grid, size_t smem, hipStream_t st, const A &args)
+{
+    if (smem > 65536) // the dim_scale 1.0 tiles need more than the default dynamic-LDS limit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), smem, st, args);
+}
+
+// one workgroup = 4 waves x 32 frames; cap the grid at 4 workgroups per CU and let waves loop
+inline unsigned mfma_grid(int64_t N)
+{
+    const int64_t blocks = ((N + 31) / 32 + 3) / 4;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
+}
+
+int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, void *workspace,
+                 int32_t *status, const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, hipStream_t st)
+{
+    const FastModel &F = *m->fast;
+    s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
+    void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
+    void **scan_events = opts ? opts->scan_events : nullptr;
+    const FastWs w = fast_ws(m, B, L);
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto I16 = [&](size_t off) { return reinterpret_cast<int16_t *>(ws + off); };
+    auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+    LayerDyn *dyn = reinterpret_cast<LayerDyn *>(ws + w.dyn);
+    const int64_t N = (int64_t)B * L;
+    const int H = m->H, P = m->P;
+    const int64_t NH = N * H;
+    const bool big = (H == 192);
+    const unsigned grid = mfma_grid(N);
+    int rc;
+    if ((rc = hip_rc(hipMemsetAsync(status, 0, sizeof(int32_t) * S5FXP_STATUS_WORDS, st)))) return rc;
+    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)m->n_layers, st)))) return rc;
+
+    int16_t *h = I16(w.hA), *hn = I16(w.hB);
+    // ---- encoder + ReLU
+    {
+        const DenseDev &e = m->enc;
+        EncArgs a{};
+        a.x = x; a.y = h; a.w = F.enc.w; a.bias_eff = F.enc.bias_eff; a.N = N; a.K = e.K; a.M = e.M;
+        a.xb = x_bits; a.xe = x_exp; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp;
+        a.conv = (x_bits > e.inp_bits || x_exp > e.inp_exp) ? 1 : 0;
+        a.rs = (a.conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp;
+        if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
+        a.out_bits = e.out_bits; a.status = status;
+        const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4; // weights + cs128 + bias_eff
+        if (big) launch_smem(k_enc_mfma<9, 6>, grid, smem, st, a);
+        else launch_smem(k_enc_mfma<9, 3>, grid, smem, st, a);
+    }
+    int hb = m->enc.out_bits;
+    DynExp he{m->enc.out_exp, nullptr};
+
+    for (int li = 0; li < m->n_layers; ++li) {
+        const LayerDev &l = m->layers[li];
+        const FastLayer &fl = F.layers[li];
+        const s5fxp_layer_trace *tr = traces ? &traces[li] : nullptr;
+        LayerDyn *d = dyn + li;
+        int32_t *st_exps = status + 8 + 8 * li;
+        const s5fxp_ssm_desc &s = l.sd;
+        auto mx = [](int a, int b) { return a > b ? a : b; };
+
+        BnArgs bn{};
+        bn.mm = l.mm; bn.isv = l.isv; bn.scale = l.scale; bn.bias = l.nbias;
+        bn.xb = hb; bn.xe = he;
+        bn.mb = l.nd.mean_bits; bn.me = l.nd.mean_exp; bn.b1 = mx(hb, bn.mb);
+        bn.ib = l.nd.invsq_var_bits; bn.ie = l.nd.invsq_var_exp; bn.b2 = mx(bn.b1, bn.ib);
+        bn.sb = l.nd.scale_bits; bn.se = l.nd.scale_exp; bn.b3 = l.scale ? mx(bn.b2, bn.sb) : bn.b2;
+        bn.bb = l.nd.bias_bits; bn.be = l.nd.bias_exp; bn.b4 = l.nbias ? mx(bn.b3, bn.bb) : bn.b3;
+        bn.ub = s.u_bits; bn.ue = s.u_exp; bn.out_bits = bn.b4; bn.dyn = d;
+
+        const unsigned rg = ew_grid(NH / 4) > 2048 ? 2048 : ew_grid(NH / 4);
+        auto hook = [&](int slot, int n) -> int {
+            return allreduce ? allreduce(allreduce_ctx, reinterpret_cast<float *>(d->mx + slot), n, (void *)st) : 0;
+        };
+        hipLaunchKernelGGL(k_bn_reduce16<1>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
+        if (hook(0, 3)) return S5FXP_EHIP;
+        hipLaunchKernelGGL(k_bn_finalize<1>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
+        hipLaunchKernelGGL(k_bn_reduce16<2>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
+        if (hook(3, 1)) return S5FXP_EHIP;
+        hipLaunchKernelGGL(k_bn_finalize<2>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
+        if (l.scale) {
+            hipLaunchKernelGGL(k_bn_reduce16<3>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
+            if (hook(4, 1)) return S5FXP_EHIP;
+            hipLaunchKernelGGL(k_bn_finalize<3>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
+        }
+        if (l.nbias) {
+            hipLaunchKernelGGL(k_bn_reduce16<4>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
+            if (hook(5, 3)) return S5FXP_EHIP;
+            hipLaunchKernelGGL(k_bn_finalize<4>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
+        }
+
+        // ---- B projection -> scan-native stream
+        const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
+        {
+            BprojMArgs a{};
+            a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq);
+            a.tr_bu_re = tr ? tr->Bu_re : nullptr; a.tr_bu_im = tr ? tr->Bu_im : nullptr;
+            a.tr_pre_s5 = tr ? tr->pre_s5 : nullptr; a.tr_u = tr ? tr->u : nullptr;
+            a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
+            a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
+            a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
+            const size_t smem = (size_t)a.w.Np * a.w.Kp + (size_t)a.w.Np * 4; // weights + cs128
+            if (big) launch_smem(k_bproj_mfma<6, 8>, grid, smem, st, a);
+            else launch_smem(k_bproj_mfma<3, 4>, grid, smem, st, a);
+        }
+        // ---- recurrence
+        ScanArgs sl{};
+        sl.bu_re = I32(w.bq); sl.a_re = l.a_re; sl.a_im = l.a_im; sl.out_re = I32(w.xs);
+        sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
+        const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
+        int32_t xmax = 32767; // the C projection's 16-bit planes
+        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
+        if (l.quad_ok) {
+            ScanQuadArgs q{};
+            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+            xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
+        } else {
+            sl.run_if = nullptr;
+            hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+        }
+        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
+        // ---- C projection + D*u + ReLU (MFMA, range check); exact 32-bit re-run if the check fails
+        {
+            CprojMArgs a{};
+            a.bn = bn; a.x = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.D = fl.Dpad;
+            a.x1 = I16(w.x1); a.tr_ys = tr ? tr->ys : nullptr; a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
+            a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
+            a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.xmax = xmax; a.dynw = d; a.status = status;
+            const size_t smem = 2 * (size_t)a.w_re.Np * a.w_re.Kp + 3 * (size_t)a.w_re.Np * 4 + 4 * 32 * (size_t)(4 * P + 16);
+            if (big) launch_smem(k_cproj_mfma<4, 6>, grid, smem, st, a);
+            else launch_smem(k_cproj_mfma<2, 3>, grid, smem, st, a);
+            if (l.quad_ok) {
+                sl.run_if = &d->redo;
+                hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+            }
+            CprojArgs g{};
+            g.bn = bn; g.x = h; g.xs = I32(w.xs); g.w_re = l.c_re_t; g.w_im = l.c_im_t; g.D = l.D;
+            g.x1 = I16(w.x1); g.tr_ys = tr ? tr->ys : nullptr; g.N = N; g.L = L; g.TB = w.TB; g.H = H; g.P = P;
+            g.mw = mw_for(H); g.rs_re = a.rs_re; g.rs_im = a.rs_im; g.rs_d = a.rs_d; g.y_bits = s.y_bits;
+            g.xmax = xmax; g.dynw = d; g.status = status;
+            const unsigned tiles = (unsigned)((N + TN - 1) / TN);
+            S5_DISPATCH_MW_C(g.mw, false, 1, int16_t, tiles, st, g);
+            if (tr && (tr->xs_re || tr->xs_im))
+                hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
+                                   tr->xs_re, tr->xs_im, B, L, P, w.TB);
+        }
+        // ---- out2 + sigmoid + gate + residual maxima
+        {
+            const DenseDev &o = l.out2;
+            GateMArgs a{};
+            a.x1 = I16(w.x1); a.skip = h; a.z = I16(w.z); a.w = fl.out2.w; a.bias_eff = fl.out2.bias_eff;
+            a.tr_out2 = tr ? tr->out2 : nullptr; a.tr_sig = tr ? tr->out2_sigmoid : nullptr;
+            a.tr_z = tr ? tr->post_GLU : nullptr;
+            a.N = N; a.H = H; a.y_bits = s.y_bits; a.y_exp = s.y_exp;
+            a.conv = (s.y_bits > o.inp_bits || s.y_exp > o.inp_exp) ? 1 : 0;
+            a.inp_bits = o.inp_bits; a.inp_exp = o.inp_exp;
+            a.rs = (a.conv ? o.inp_exp : s.y_exp) + o.w_exp - o.out_exp;
+            if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
+            a.out_bits = o.out_bits; a.out_exp = o.out_exp; a.sig_x = l.sig_x; a.sig_y = l.sig_y;
+            std::memcpy(a.lut, l.lut, sizeof(a.lut));
+            a.l_bits = l.l_bits; a.l_exp = l.l_exp; a.r_bits = l.r_bits; a.r_exp = l.r_exp; a.res_bits = l.res_bits;
+            a.res_exp = l.res_exp; a.rs_gate = l.l_exp + l.r_exp - l.res_exp; a.skip_e = he; a.dynw = d;
+            const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4 + 32; // + lut
+            if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem, st, a);
+            else launch_smem(k_out2gate_mfma<3, 3>, grid, smem, st, a);
+        }
+        if (hook(8, 3)) return S5FXP_EHIP;
+        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps);
+        hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z), (const int16_t *)h,
+                           hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
+        int16_t *sw = h; h = hn; hn = sw;
+        hb = l.res_bits;
+        he = DynExp{0, &d->res.eo};
+    }
+    // ---- decoder
+    {
+        const DenseDev &e = m->dec;
+        DecArgs a{};
+        a.x = h; a.y = y; a.w = F.dec.w; a.bias_eff = F.dec.bias_eff; a.N = N; a.H = H; a.M = e.M;
+        a.xb = hb; a.xe = he; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.w_exp = e.w_exp;
+        a.out_bits = e.out_bits; a.out_exp = e.out_exp; a.status = status;
+        const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4;
+        if (big) launch_smem(k_dec_mfma<6, 3, 3>, grid, smem, st, a);
+        else launch_smem(k_dec_mfma<3, 3, 3>, grid, smem, st, a);
+    }
+    return launch_rc();
+}
+
+} // namespace

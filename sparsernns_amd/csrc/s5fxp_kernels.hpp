@@ -513,11 +513,11 @@ __global__ void k_unpack_native(const int32_t *__restrict__ stream, int32_t *__r
 // ---------------------------------------------------------------------------------------------
 struct CprojArgs {
     BnArgs bn;
-    const int32_t *x;          // (N,H) layer input (for u)
+    const void *x;             // (N,H) layer input (for u), element type AT
     const int32_t *xs;         // native stream of raw states
     const int32_t *w_re, *w_im; // (P,H)
     const int32_t *D;          // (H)
-    int32_t *x1;               // (N,H) relu(ys)
+    void *x1;                  // (N,H) relu(ys), element type AT
     int32_t *tr_ys;            // optional (N,H)
     int64_t N;
     int32_t L, TB;
@@ -528,7 +528,8 @@ struct CprojArgs {
     int32_t *status;
 };
 
-template <int MWMAX, bool X24, int PASS>
+// AT = storage type of the (N,H) activations: int32_t (generic path) or int16_t (MFMA path's fallback)
+template <int MWMAX, bool X24, int PASS, typename AT>
 __global__ __launch_bounds__(256) void k_cproj(CprojArgs a)
 {
     __shared__ MMShared<MWMAX> S;
@@ -565,11 +566,11 @@ __global__ __launch_bounds__(256) void k_cproj(CprojArgs a)
             const int32_t ci = sat(asr(S.out[nl][m], a.rs_im), a.y_bits);
             const int32_t cx = sat(wadd(cr, wmul(ci, -1)), a.y_bits);
             const int32_t cx2 = wmul(cx, 2); // not clipped, fxpmodel.py:765-767
-            const int32_t u = bn_chain<5>(a.bn, d, a.x[n * a.H + m], m);
+            const int32_t u = bn_chain<5>(a.bn, d, (int32_t) reinterpret_cast<const AT *>(a.x)[n * a.H + m], m);
             const int32_t du = sat(asr(wmul(a.D[m], u), a.rs_d), a.y_bits);
             const int32_t y = sat(wadd(cx2, du), a.y_bits);
             if (a.tr_ys) a.tr_ys[n * a.H + m] = y;
-            a.x1[n * a.H + m] = y < 0 ? 0 : y;
+            reinterpret_cast<AT *>(a.x1)[n * a.H + m] = (AT)(y < 0 ? 0 : y);
         }
     }
 }

@@ -272,12 +272,18 @@ def derive_qconfig(modeldict: dict, stats: dict, n_layers: int, precisions: dict
 
 def make_model(dim_scale: float = 0.5, seed: int = 1919, quantization: str = "w8a16", sparsity: float = 0.0,
                calib_B: int = 2, calib_L: int = 256, input_scale: float = 1.0, bn_stats: str = "calibrated",
-               bn_scale_bias: bool = False, dims: Optional[dict] = None) -> Tuple[dict, dict, dict]:
+               bn_scale_bias: bool = False, dims: Optional[dict] = None,
+               state_headroom_bits: int = 0) -> Tuple[dict, dict, dict]:
     """Returns (modeldict, fxp_qconfig, dims).
 
     bn_stats="calibrated": BatchNorm running mean/var are set to the statistics of the layer
     input on the calibration batch (what training would leave behind), so activations use the
     full 16-bit range; "random": mean ~ N(0,0.1), var ~ U(0.5,1.5) as drawn.
+
+    state_headroom_bits: extra integer bits for the SSM state (x_re/x_im exponents lowered by that
+    much).  The reference never clips the state (fxpmodel.py:147-172), and the fixed-point model
+    drifts from the float calibration run through its saturation quirks, so a float-calibrated state
+    exponent can be exceeded on long sequences; a deployment would calibrate with this margin.
     """
     dims = dict(dims) if dims is not None else ndns_dims(dim_scale)
     md = make_float_params(dims, seed, bn_scale_bias)
@@ -287,6 +293,8 @@ def make_model(dim_scale: float = 0.5, seed: int = 1919, quantization: str = "w8
     xcal = make_input(calib_B, calib_L, dims["d_in"], seed=seed + 1, scale=input_scale)
     float_forward(md, xcal, dims["n_layers"], calibrate_bn=(bn_stats == "calibrated"), stats=stats)
     qc = derive_qconfig(md, stats, dims["n_layers"], PRECISIONS[quantization])
+    for k in ("x_re", "x_im"):
+        qc["blocks"]["ssm"]["activations"][k]["exp"] -= state_headroom_bits
     _assert_exps_nonnegative(qc)
     return md, qc, dims
 
