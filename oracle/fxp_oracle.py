@@ -151,6 +151,13 @@ def intbits_f32(m, eps) -> int:
 # --------------------------------------------------------------------------------------
 # fxparray.py ops
 # --------------------------------------------------------------------------------------
+# Test hook for the multi-rank protocol (SURVEY.md §8e mode A): when set, every compute_best op passes
+# its float32 maxima through it (e.g. an all_reduce(MAX) over ranks) before choosing the exponent.
+MAX_EXCHANGE = None
+
+
+def _exchange_max(v: np.ndarray) -> np.ndarray:
+    return v if MAX_EXCHANGE is None else np.asarray(MAX_EXCHANGE(v), dtype=F32)
 def from_fp(x, bits=16, exp=8, signed=True, mode=FLOOR) -> Fx:
     """fxparray.py:287-307.  x is float32."""
     x = np.asarray(x, dtype=F32)
@@ -210,10 +217,11 @@ def add(a: Fx, b: Fx, result_bits: Optional[int] = None, result_exp=None, mode: 
     elif isinstance(result_exp, str):
         assert result_exp == "compute_best"
         fa, fb = a.f32(), b.f32()
-        m = np.abs((fa + fb).astype(F32)).max()
+        mx3 = _exchange_max(np.array([np.abs((fa + fb).astype(F32)).max(), np.abs(fa).max(), np.abs(fb).max()], dtype=F32))
+        m = mx3[0]
         ib = intbits_f32(m, 1e-6)
         result_exp = result_bits - ib - (1 if signed else 0)
-        ia = max(intbits_f32(np.abs(fa).max(), 1e-8), intbits_f32(np.abs(fb).max(), 1e-8))
+        ia = max(intbits_f32(mx3[1], 1e-8), intbits_f32(mx3[2], 1e-8))
         agg_exp = max(a.exp, b.exp)
         agg_bits = ia + agg_exp + (1 if signed else 0)
         ac = change_cfg(a, max(agg_bits, a.bits), agg_exp, signed)
@@ -249,7 +257,7 @@ def mul(a: Fx, b: Fx, result_bits: Optional[int] = None, result_exp=None, mode: 
         result_exp = max(a.exp, b.exp)
     elif isinstance(result_exp, str):
         assert result_exp == "compute_best"
-        m = np.abs((a.f32() * b.f32()).astype(F32)).max()
+        m = _exchange_max(np.array([np.abs((a.f32() * b.f32()).astype(F32)).max()], dtype=F32))[0]
         ib = intbits_f32(m, 1e-6)
         result_exp = result_bits - ib - (1 if signed else 0)
     rshift = a.exp + b.exp - result_exp

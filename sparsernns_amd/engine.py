@@ -136,9 +136,13 @@ class Engine:
                         setattr(tr[i], k, d[k].data_ptr())
         opts = _lib.ForwardOpts()
         if allreduce is not None:
+            ws_base = ws.data_ptr()
+
             def _cb(ctx, dev_ptr, n, stream):  # noqa: ANN001
                 try:
-                    allreduce(int(dev_ptr), int(n), int(stream) if stream else 0)
+                    # the maxima live in the workspace: hand the hook a float32 view of exactly those n words
+                    off = int(dev_ptr) - ws_base
+                    allreduce(ws[off:off + 4 * int(n)].view(torch.float32))
                     return 0
                 except Exception:  # pragma: no cover - surfaced as EHIP by the C side
                     import traceback

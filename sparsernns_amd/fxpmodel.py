@@ -574,6 +574,7 @@ class FxpRegressionModel(FxpModule):  # :1380-1458
         self.decoder = FxpDense(modeldict=self.modeldict["decoder"], fxp_qconfig=self.fxp_qconfig["decoder"],
                                 scope=self.scope + ".decoder", store_intermediates=self.store_intermediates)
         self._engine = None
+        self._generic_engine = None
 
     # -- fused path -----------------------------------------------------------------------------
     def engine(self):
@@ -591,7 +592,15 @@ class FxpRegressionModel(FxpModule):  # :1380-1458
             y = self.decoder(h)
             self.sow("intermediates", "output", y)
             return y
-        return self.engine().forward(x, allreduce=self.exponent_allreduce)
+        try:
+            return self.engine().forward(x, allreduce=self.exponent_allreduce)
+        except OverflowError:
+            # the input holds values beyond its nominal bits (legal in the reference): 32-bit kernels
+            from ._lib import MODEL_FORCE_GENERIC
+            from .engine import Engine
+            if self._generic_engine is None:
+                self._generic_engine = Engine(self.export(), flags=self.engine_flags | MODEL_FORCE_GENERIC)
+            return self._generic_engine.forward(x, allreduce=self.exponent_allreduce)
 
     def export(self):
         encoder_data, decoder_data = self.encoder.export(), self.decoder.export()

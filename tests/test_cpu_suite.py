@@ -1,0 +1,325 @@
+"""CPU-only tests (`-m "not gpu"`): the two oracle halves against each other and against the committed
+golden fixtures, the host-side setup logic of the product against the oracle, the C-ABI library
+(loads, exports every declared symbol, validates arguments), and the 2-rank protocol over gloo.
+No GPU compute is called here.
+"""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import fxp_oracle as O
+from sparsernns_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+GOLDEN = ["tiny_a", "tiny_b_bnscale", "ndns05_short"]
+
+
+def unflatten(flat):
+    tree = {}
+    for k, v in flat.items():
+        node = tree
+        parts = k.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = v
+    return tree
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    meta = json.load(open(os.path.join(GOLD, f"{name}.json")))
+    md = unflatten({k[3:]: z[k] for k in z.files if k.startswith("md/")})
+    params = unflatten({k[7:]: z[k].astype(np.int32) for k in z.files if k.startswith("params/")})
+    inter = {k[6:]: z[k] for k in z.files if k.startswith("inter/")}
+    export = dict(params=params, qconfig=meta["export_qconfig"])
+    return md, meta, export, z["x"].astype(np.int32), z["y"].astype(np.int32), inter
+
+
+# ------------------------------------------------------------------------------------------
+# oracle vs golden, oracle vs oracle
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", GOLDEN)
+def test_oracles_reproduce_golden(name):
+    md, meta, export, x, y, inter = load_golden(name)
+    # scalar C half, from the integer model
+    yc, yb, ye, tr = cref.CModel(export).forward(x, meta["x_bits"], meta["x_exp"], trace=True)
+    assert (yb, ye) == (meta["y_bits"], meta["y_exp"])
+    assert np.array_equal(yc, y)
+    names = dict(xs_re="mixer.xs_re", bu_im="mixer.Bu_im", ys="mixer.ys", residadd="residadd")
+    for i, t in enumerate(tr):
+        for ck, gk in names.items():
+            key = f"layers_{i}.{gk}"
+            if key in inter:
+                assert np.array_equal(t[ck], inter[key]), key
+        assert t["residadd_exp"] == meta["inter"][f"layers_{i}.residadd"][1]
+    # NumPy half, from the float model (small fixtures carry the float parameters)
+    if md:
+        model = O.RegressionModel(md, meta["qconfig"], meta["dims"]["n_layers"])
+        it = {}
+        yo = model(O.Fx(x, meta["x_bits"], meta["x_exp"]), it)
+        assert np.array_equal(yo.data, y)
+        fl = O.flatten_intermediates(it)
+        for k, v in inter.items():
+            assert np.array_equal(fl[k].data, v), k
+            assert [fl[k].bits, fl[k].exp] == meta["inter"][k], k
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_numpy_and_c_oracles_agree_on_random_models(seed):
+    rng = np.random.default_rng(seed)
+    H = int(rng.choice([8, 12, 16]))
+    P = int(rng.choice([4, 6, 8]))
+    dims = synth.tiny_dims(H=H, P=P, d_in=int(rng.integers(3, 9)), d_out=int(rng.integers(2, 9)), n_layers=int(rng.integers(1, 4)))
+    scale = float(rng.choice([1.0, 30.0, 300.0]))
+    md, qc, dims = synth.make_model(dims=dims, seed=100 + seed, bn_scale_bias=bool(seed % 2), input_scale=scale,
+                                    bn_stats="random" if seed == 3 else "calibrated")
+    B, L = int(rng.integers(1, 4)), int(rng.integers(1, 70))
+    x = synth.make_input(B, L, dims["d_in"], seed=seed, scale=scale)
+    fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+    m = O.RegressionModel(md, qc, dims["n_layers"])
+    it = {}
+    y = m(fx, it)
+    yc, yb, ye, tr = cref.CModel(m.export()).forward(fx.data, fx.bits, fx.exp, trace=True)
+    assert (yb, ye) == (y.bits, y.exp)
+    assert np.array_equal(yc, y.data)
+    fl = O.flatten_intermediates(it)
+    names = dict(pre_s5="pre_s5", u="mixer.u", bu_re="mixer.Bu_re", xs_im="mixer.xs_im", ys="mixer.ys", out2="out2",
+                 sigmoid="out2_sigmoid", post_glu="post_GLU", residadd="residadd")
+    for i in range(dims["n_layers"]):
+        for ck, ok in names.items():
+            assert np.array_equal(tr[i][ck], fl[f"layers_{i}.{ok}"].data), (i, ck)
+    # a 2-D (L, d_in) input is the same computation as a batch of one (fxprun.py:531)
+    y1, _, _, _ = cref.CModel(m.export()).forward(fx.data[0], fx.bits, fx.exp)
+    assert np.array_equal(y1, y.data[0]) or B > 1  # with B > 1 the batch couples through compute_best
+
+
+def test_float_log2_path_matches_definition_away_from_powers_of_two():
+    """The reference evaluates log(x)/log(2) in float32; away from powers of two that agrees with the
+    oracle's correctly rounded log2 (the documented ambiguity is confined to a few ulp above 2^k)."""
+    rng = np.random.default_rng(5)
+    v = np.exp(rng.uniform(np.log(1e-6), np.log(6e4), 20000)).astype(np.float32)
+    frac = np.abs(np.log2(v.astype(np.float64)) - np.rint(np.log2(v.astype(np.float64))))
+    v = v[frac > 1e-5]
+    jaxlike = np.ceil((np.log(v) / np.float32(np.log(np.float32(2)))).astype(np.float32))
+    ours = np.array([O.ceil_log2_f32(t) for t in v], dtype=np.float32)
+    assert np.array_equal(jaxlike, ours)
+
+
+# ------------------------------------------------------------------------------------------
+# product host logic vs oracle (no GPU: setup is host NumPy)
+# ------------------------------------------------------------------------------------------
+def tree_equal(a, b, path=""):
+    assert isinstance(a, dict) == isinstance(b, dict), path
+    if isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            tree_equal(a[k], b[k], f"{path}/{k}")
+    elif isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        assert np.array_equal(np.asarray(a), np.asarray(b)), path
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.parametrize("cfg", [dict(dims=synth.tiny_dims()), dict(dims=synth.tiny_dims(H=12, P=6, n_layers=3), bn_scale_bias=True),
+                                 dict(dim_scale=0.5), dict(dim_scale=0.5, sparsity=0.9), dict(dim_scale=1.0, quantization="w8a8", bn_stats="random", input_scale=300.0)])
+def test_product_setup_quantises_like_the_oracle(cfg):
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = synth.make_model(**cfg)
+    prod = build_regression_model(md, qc, dims["n_layers"]).export()
+    orc = O.RegressionModel(md, qc, dims["n_layers"]).export()
+    tree_equal(prod["params"], orc["params"], "params")
+    # the product's qconfig carries the reference's extra *_signed keys; everything the oracle has must match
+    def sub(a, b, path=""):
+        for k, v in b.items():
+            if isinstance(v, dict):
+                sub(a[k], v, f"{path}/{k}")
+            else:
+                assert a[k] == v, (path, k)
+    sub(prod["qconfig"], orc["qconfig"])
+    if cfg.get("sparsity"):
+        w = prod["params"]["encoder"]["encoder"]["weight"]
+        assert 0.85 < np.mean(w == 0) < 0.97  # zeros stored densely, as jaxpruner leaves them
+
+
+def test_model_rejects_what_the_reference_rejects():
+    from sparsernns_amd.fxpmodel import FxpSSM, build_regression_model
+
+    md, qc, dims = synth.make_model(dims=synth.tiny_dims())
+    with pytest.raises(AssertionError):
+        build_regression_model(md, qc, dims["n_layers"], glu_variant="bogus")
+    with pytest.raises(NotImplementedError):
+        build_regression_model(md, qc, dims["n_layers"], glu_variant="full")
+    with pytest.raises(AssertionError):  # fxpmodel.py:430-432
+        FxpSSM.init_fn(H=8, P=4, discretization="zoh", associative_scan=True)(
+            modeldict=md["encoder"]["layers_0"]["mixer"], fxp_qconfig=qc["blocks"]["ssm"], scope="m", store_intermediates=False)
+    from sparsernns_amd.fxpmodel import FxpRegressionModel, QuantizationConfig
+    with pytest.raises(NotImplementedError):  # the reference's fused-BN branch cannot run (fxpmodel.py:537-549)
+        FxpRegressionModel(modeldict=md, fxp_qconfig=qc, scope="model", mixer_cls=FxpSSM.init_fn(H=8, P=4, discretization="zoh"),
+                           n_layers=2, d_model=8, batchnorm=True, prenorm=True, glu_variant="half1", relufication=True,
+                           fuse_batchnorm_linear=True, q_config=QuantizationConfig.none(), dropout=0.0, training=False,
+                           store_intermediates=False)
+
+
+def test_synth_qconfig_rules():
+    # fxputils.py:137-142: an exact power of two needs one more integer bit
+    assert [synth.get_intbits(v) for v in (0.3, 1.0, 1.5, 2.0, 3.99, 4.0)] == [0, 1, 1, 2, 2, 3]
+    # utils/quantization.py:352-370 + fxputils.py:404-450: exp = min(fracbits, bits - 1 - intbits)
+    e = synth._entry(3.7, 16)
+    assert (e["intbits"], e["fracbits"], e["exp"]) == (2, 13, 13)
+    e = synth._entry(0.0047, 16)
+    assert e["exp"] == 15 and e["fracbits"] == 23
+    assert synth.ndns_dims(0.5) == dict(H=96, P=64, blocks=8, block_size=16, n_layers=3, d_in=257, d_out=257)
+    assert synth.ndns_dims(1.0)["H"] == 192 and synth.ndns_dims(1.0)["P"] == 128
+    lam, V = synth.hippo_dplr(16)
+    assert np.allclose(lam.real, -0.5) and np.allclose(V.conj().T @ V, np.eye(16), atol=1e-9)
+    with pytest.raises(ValueError):
+        synth.make_model(dim_scale=0.5, quantization="w4a8")  # calibrated BN at 8 bits -> negative exponent
+
+
+def test_shard_bounds():
+    from sparsernns_amd.dist import shard_bounds
+
+    for total in (0, 1, 7, 32, 512):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+# ------------------------------------------------------------------------------------------
+# the C ABI: the library loads without a GPU, exports every declared symbol, validates arguments
+# ------------------------------------------------------------------------------------------
+def test_library_exports_every_symbol_in_the_header():
+    from sparsernns_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "s5fxp.h")).read()
+    declared = set(re.findall(r"\b(s5fxp_[a-z0-9_]+)\s*\(", hdr)) - {"s5fxp_allreduce_max_fn"}
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} is declared in include/s5fxp.h but not exported by libs5fxp.so"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.lib.s5fxp_version() == 100
+    assert _lib.lib.s5fxp_strerror(-2).decode().startswith("negative")
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Every entry point checks its arguments before it touches the device."""
+    from sparsernns_amd import _lib
+    from sparsernns_amd._lib import lib
+
+    assert lib.s5fxp_from_fp(None, None, 4, 16, 8, 0, None) == _lib.S5FXP_EBADARG
+    assert lib.s5fxp_change_cfg(1, 1, 4, 16, 40, 16, 2, None) == _lib.S5FXP_ENEGSHIFT
+    assert lib.s5fxp_mul(1, 1, 1, 4, 4, 3, 3, 16, 9, None) == _lib.S5FXP_ENEGSHIFT  # fxparray.py:619-621
+    assert lib.s5fxp_add(1, 1, 1, 6, 4, 16, 3, 16, 3, 16, 3, 0, None) == _lib.S5FXP_EBADARG  # 6 % 4 != 0
+    assert lib.s5fxp_dense(1, 1, None, 1, 8, 4, 4000, 3, 3, 0, 0, 16, 2, 0, None) == _lib.S5FXP_EUNSUPPORTED
+    assert lib.s5fxp_scan(1, 1, 1, 1, 1, 1, 2, 8, 0, 15, 15, 15, 15, 14, 14, 0, None) == _lib.S5FXP_EBADARG
+    assert lib.s5fxp_model_blob_bytes(None) == 0
+    with pytest.raises(ValueError):
+        _lib.check(_lib.S5FXP_ENEGSHIFT, "x")
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.S5FXP_EUNSUPPORTED, "x")
+    with pytest.raises(_lib.S5FxpError):
+        _lib.check(_lib.S5FXP_EHIP, "x")
+
+
+def test_model_descriptor_validation_on_the_host():
+    """s5fxp_model_blob_bytes runs the same validation as create() and needs no GPU."""
+    from sparsernns_amd import _lib
+    from sparsernns_amd.engine import Engine
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = synth.make_model(dim_scale=0.5)
+    export = build_regression_model(md, qc, dims["n_layers"]).export()
+    eng = Engine.__new__(Engine)  # descriptor construction only (no device)
+    eng._keep = []
+    eng.n_layers = 3
+    eng._layers = (_lib.LayerDesc * 3)()
+    for i in range(3):
+        eng._fill_layer(eng._layers[i], export["params"]["encoder"][f"layers_{i}"], export["qconfig"]["encoder"][f"layers_{i}"])
+    desc = _lib.ModelDesc()
+    desc.n_layers = 3
+    desc.encoder = eng._dense(export["params"]["encoder"]["encoder"], export["qconfig"]["encoder"]["encoder"])
+    desc.layers = C.cast(eng._layers, C.POINTER(_lib.LayerDesc))
+    desc.decoder = eng._dense(export["params"]["decoder"], export["qconfig"]["decoder"])
+    nbytes = _lib.lib.s5fxp_model_blob_bytes(C.byref(desc))
+    assert nbytes > 4 * (257 * 96 * 2 + 3 * (4 * 64 * 96 + 96 * 96))
+    # a negative static shift is what the reference turns into a ValueError: rejected at build time
+    eng._layers[1].ssm.y_exp = 31
+    assert _lib.lib.s5fxp_model_blob_bytes(C.byref(desc)) == 0
+    h = C.c_void_p()
+    assert _lib.lib.s5fxp_model_create(C.byref(desc), 1, 1 << 30, 0, None, C.byref(h)) == _lib.S5FXP_ENEGSHIFT
+
+
+def test_importing_without_the_extension_fails_loudly(tmp_path):
+    code = ("import importlib.util, sys, os\n"
+            "spec = importlib.util.spec_from_file_location('lib_copy', sys.argv[1])\n"
+            "m = importlib.util.module_from_spec(spec)\n"
+            "try:\n    spec.loader.exec_module(m)\nexcept ImportError as e:\n    print('LOUD', e)\n")
+    src = open(os.path.join(ROOT, "sparsernns_amd", "_lib.py")).read()
+    p = tmp_path / "lib_copy.py"
+    p.write_text(src)  # next to it there is no libs5fxp.so
+    out = subprocess.run([sys.executable, "-c", code, str(p)], capture_output=True, text=True)
+    assert "LOUD" in out.stdout and "no CPU fallback" in out.stdout.replace("\n", " ")
+
+
+# ------------------------------------------------------------------------------------------
+# 2-rank protocol over gloo (world_size 2, CPU): batch sharding + exponent all-reduce + output gather
+# ------------------------------------------------------------------------------------------
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from oracle import fxp_oracle as O
+from sparsernns_amd import synth
+from sparsernns_amd.dist import shard_bounds, make_exponent_allreduce, gather_outputs
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+md, qc, dims = synth.make_model(dims=synth.tiny_dims(H=12, P=6, d_in=7, d_out=9, n_layers=2), bn_scale_bias=True, input_scale=30.0)
+B, L = 6, 33
+x = synth.make_input(B, L, dims["d_in"], seed=4, scale=30.0)
+fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+model = O.RegressionModel(md, qc, dims["n_layers"])
+full = model(fx).data                                   # one reference run over the whole batch
+lo, hi = shard_bounds(B, world, rank)
+mine = O.Fx(fx.data[lo:hi], fx.bits, fx.exp)
+hook = make_exponent_allreduce()
+def exchange(v):                                        # mode A: all_reduce(MAX) of the compute_best maxima
+    t = torch.from_numpy(np.array(v, dtype=np.float32))
+    hook(t)
+    return t.numpy()
+O.MAX_EXCHANGE = exchange
+y_global = model(mine).data
+O.MAX_EXCHANGE = None
+y_local = model(mine).data                              # mode B: the shard is its own reference batch
+out = gather_outputs(torch.from_numpy(y_global.copy()))
+ok_a = bool(np.array_equal(out.numpy(), full))          # N ranks == one run over the concatenated batch
+ok_b = bool(np.array_equal(y_local, O.RegressionModel(md, qc, dims["n_layers"])(mine).data))
+differs = bool(not np.array_equal(y_local, full[lo:hi]))
+print(f"RANK{rank} modeA={ok_a} modeB={ok_b} coupled={differs}", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_protocol_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"RANK{r} modeA=True modeB=True" in o, o

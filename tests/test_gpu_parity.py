@@ -251,3 +251,84 @@ def test_compute_best_thresholds_near_powers_of_two():
             ref = O.add(O.Fx(a, 24, 6), O.Fx(z, 24, 6), None, "compute_best")
             assert got.exp == ref.exp, (k, delta, got.exp, ref.exp)
             assert np.array_equal(got.numpy(), ref.data)
+
+
+# ------------------------------------------------------------------------------------------
+# golden fixtures, fallbacks, hooks
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b_bnscale", "ndns05_short"])
+def test_golden_fixtures_on_gpu(name):
+    from sparsernns_amd.engine import Engine
+    from sparsernns_amd.fxparray import FxpArray
+    from tests.test_cpu_suite import load_golden
+
+    md, meta, export, x, y, inter = load_golden(name)
+    eng = Engine(export)
+    got, tr = eng.forward(FxpArray(x, meta["x_bits"], meta["x_exp"]), traces=True)
+    assert (got.bits, got.exp) == (meta["y_bits"], meta["y_exp"])
+    assert np.array_equal(got.numpy(), y)
+    names = dict(xs_re="mixer.xs_re", Bu_im="mixer.Bu_im", ys="mixer.ys", residadd="residadd")
+    for i in range(eng.n_layers):
+        for gk, ok in names.items():
+            key = f"layers_{i}.{ok}"
+            if key in inter:
+                assert np.array_equal(tr[i][gk].cpu().numpy(), inter[key]), key
+
+
+def test_state_overflow_takes_the_exact_fallback():
+    """States beyond the fast recurrence kernel's exactness bound: the range check must fire and the
+    32-bit kernels must reproduce the oracle (the reference never clips the state, fxpmodel.py:147-172)."""
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    fx = _input(qc, dims, 2, 512, seed=9, scale=6.0)  # calibrated at scale 1
+    ref, _, _, rtr = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp, trace=True)
+    assert max(int(np.abs(t["xs_re"]).max()) for t in rtr) > 32767, "the case must overflow 16 bits to mean anything"
+    eng = model.engine()
+    assert _lib.lib.s5fxp_model_is_fast(eng._h) == 1
+    y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))
+    assert int(eng.status[0].item()) & _lib.ST_WIDE_STATE
+    assert np.array_equal(y.numpy(), ref)
+    # and the all-generic engine agrees as well
+    gen = build_regression_model(md, qc, dims["n_layers"], engine_flags=_lib.MODEL_FORCE_GENERIC)
+    assert _lib.lib.s5fxp_model_is_fast(gen.engine()._h) == 0
+    assert np.array_equal(gen(FxpArray(fx.data, fx.bits, fx.exp)).numpy(), ref)
+
+
+def test_unclipped_input_is_rerun_on_the_generic_kernels():
+    """An FxpArray may hold data beyond its nominal bits (the reference never checks): the MFMA encoder
+    flags it and the model re-runs on the 32-bit kernels."""
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    fx = _input(qc, dims, 1, 64, seed=2)
+    data = fx.data.copy()
+    data[0, 5, 7] = 70000
+    data[0, 40, 200] = -(1 << 25)
+    ref, _, _, _ = cref.CModel(model.export()).forward(data, fx.bits, fx.exp)
+    y = model(FxpArray(data, fx.bits, fx.exp))
+    assert np.array_equal(y.numpy(), ref)
+
+
+def test_exponent_hook_is_called_per_compute_best_op():
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    fx = _input(qc, dims, 2, 64, seed=3)
+    ref = model(FxpArray(fx.data, fx.bits, fx.exp)).numpy()
+    calls = []
+
+    def hook(t):
+        assert t.dtype.is_floating_point and t.is_cuda
+        calls.append(int(t.numel()))
+
+    y = model.engine().forward(FxpArray(fx.data, fx.bits, fx.exp), allreduce=hook)
+    assert np.array_equal(y.numpy(), ref)
+    assert calls == [3, 1, 3] * dims["n_layers"]  # BN add, BN mul, residual add (no scale/bias in this model)
