@@ -1,0 +1,346 @@
+// mfma_bn.hpp -- BatchNorm exponents from per-channel extremes, and the lean B projection.
+//
+// (1) The four BatchNorm ops pick their exponents from float32 maxima over the whole (B,L,H) tensor
+//     (fxpmodel.py:892-933, fxparray.py:421-432,602-608).  Per channel h every stage is a MONOTONE map of
+//     the layer input x (shift, saturate, add a constant, multiply by a constant, floor shift -- no int32
+//     wrap while all operands are <= 16 bit with exponents in [0,15], which the host checks), int32->float32
+//     and float32 add/mul by a constant are monotone as well, and |.| of a monotone function peaks at an end
+//     point.  So max over the tensor = max over channels of the two end points min_h(x), max_h(x): ONE pass
+//     over the tensor (k_minmax16) and one single-workgroup kernel (k_bn_finalize_mm) replace four reduction
+//     passes.  The results are identical by construction; tests compare against the oracle's full reductions.
+//
+// (2) k_bproj_mfma2: same arithmetic as k_bproj_mfma, but BatchNorm parameters come from LDS, the chain runs
+//     four elements at a time (bounded live registers), traces are compiled out unless requested, and the
+//     SSM input u is written once (int16) so the C projection does not recompute the chain.
+#pragma once
+#include "mfma_proj.hpp"
+
+namespace s5 {
+
+// ---------------------------------------------------------------------------------------------
+// per-channel extremes of an int16 (N,H) tensor as POSITIVE floats: ext[h] = 65536 - min_h, ext[H+h] =
+// 65536 + max_h (exact for 16-bit data).  Zero-initialised by a memset; atomicMax on the bit pattern;
+// the multi-rank hook (element-wise float MAX) can exchange them as they are.
+// ---------------------------------------------------------------------------------------------
+constexpr float EXT_BIAS = 65536.f;
+
+// block = 256 threads = G channel-groups (4 channels each) x R frame lanes; G = H/4 (24 or 48)
+__global__ __launch_bounds__(256) void k_minmax16(const int16_t *__restrict__ x, int64_t N, int H, float *ext)
+{
+    __shared__ int32_t smin[256 * 4], smax[256 * 4];
+    const int G = H >> 2, R = 256 / G;
+    const int g = threadIdx.x % G, rl = threadIdx.x / G;
+    int32_t lo[4] = {32767, 32767, 32767, 32767}, hi[4] = {-32768, -32768, -32768, -32768};
+    if (rl < R) {
+        for (int64_t n = (int64_t)blockIdx.x * R + rl; n < N; n += (int64_t)gridDim.x * R) {
+            int32_t v[4];
+            unpack4_i16(*reinterpret_cast<const v2i *>(x + n * H + 4 * g), v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = v[e] < lo[e] ? v[e] : lo[e];
+                hi[e] = v[e] > hi[e] ? v[e] : hi[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        smin[threadIdx.x * 4 + e] = lo[e];
+        smax[threadIdx.x * 4 + e] = hi[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < H) { // one thread per channel folds the R frame lanes
+        const int c = threadIdx.x, cg = c >> 2, ce = c & 3;
+        int32_t a = 32767, b = -32768;
+        for (int r = 0; r < R; ++r) {
+            const int t = r * G + cg;
+            a = min(a, smin[t * 4 + ce]);
+            b = max(b, smax[t * 4 + ce]);
+        }
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)a));
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + H + c, __float_as_uint(EXT_BIAS + (float)b));
+    }
+}
+
+// block reduce of NV float maxima over blockDim.x threads (every thread gets the result)
+template <int NV>
+__device__ __forceinline__ void block_allmax(float (&v)[NV], float (*red)[8])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float t = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+        if (lane == 0) red[i][wave] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float t = red[i][0];
+        for (int w = 1; w < nw; ++w) t = fmaxf(t, red[i][w]);
+        v[i] = t;
+    }
+    __syncthreads();
+}
+
+// One workgroup (256 threads >= H): thread h owns channel h and walks its two end points through the
+// BatchNorm stages; between stages the workgroup reduces the maxima and thread 0 derives the exponent.
+__global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *ext, int H, LayerDyn *d, int32_t *status,
+                                                        int32_t *status_exps)
+{
+    __shared__ float red[3][8];
+    __shared__ LayerDyn sd;
+    const int h = threadIdx.x;
+    const bool act = h < H;
+    const int32_t xlo = act ? (int32_t)(EXT_BIAS - ext[h]) : 0, xhi = act ? (int32_t)(ext[H + h] - EXT_BIAS) : 0;
+    const int xe = a.xe.get();
+    if (h == 0) sd = *d;
+    __syncthreads();
+    // ---- stage 1: x + (-mean)        fxpmodel.py:892-897
+    {
+        float v[3] = {0.f, 0.f, 0.f};
+        if (act) {
+            const float fm = tofloat(a.mm[h], a.me), f0 = tofloat(xlo, xe), f1 = tofloat(xhi, xe);
+            v[0] = fmaxf(fabsf(__fadd_rn(f0, fm)), fabsf(__fadd_rn(f1, fm)));
+            v[1] = fmaxf(fabsf(f0), fabsf(f1));
+            v[2] = fabsf(fm);
+        }
+        block_allmax<3>(v, red);
+        if (h == 0) {
+            uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
+            sd.mx[0] = m3[0]; sd.mx[1] = m3[1]; sd.mx[2] = m3[2];
+            sd.bn1 = finalize_add_cb(m3, xe, a.me, a.b1, status);
+            sd.bn_e = sd.bn1.eo;
+            status_exps[0] = sd.bn1.eo;
+        }
+        __syncthreads();
+    }
+    // ---- stage 2: * invsq_var        fxpmodel.py:902-907
+    {
+        float v[1] = {0.f};
+        if (act) {
+            const float fi = tofloat(a.isv[h], a.ie);
+            const float f0 = tofloat(bn_chain<1>(a, sd, xlo, h), sd.bn1.eo), f1 = tofloat(bn_chain<1>(a, sd, xhi, h), sd.bn1.eo);
+            v[0] = fmaxf(fabsf(__fmul_rn(f0, fi)), fabsf(__fmul_rn(f1, fi)));
+        }
+        block_allmax<1>(v, red);
+        if (h == 0) {
+            sd.mx[3] = __float_as_uint(v[0]);
+            finalize_mul_cb(sd.mx[3], sd.bn1.eo, a.ie, a.b2, sd.rs2, sd.e2, status);
+            sd.bn_e = sd.e2;
+            status_exps[1] = sd.e2;
+        }
+        __syncthreads();
+    }
+    // ---- stage 3: * scale            fxpmodel.py:915-920
+    if (a.scale) {
+        float v[1] = {0.f};
+        if (act) {
+            const float fs = tofloat(a.scale[h], a.se);
+            const float f0 = tofloat(bn_chain<2>(a, sd, xlo, h), sd.e2), f1 = tofloat(bn_chain<2>(a, sd, xhi, h), sd.e2);
+            v[0] = fmaxf(fabsf(__fmul_rn(f0, fs)), fabsf(__fmul_rn(f1, fs)));
+        }
+        block_allmax<1>(v, red);
+        if (h == 0) {
+            sd.mx[4] = __float_as_uint(v[0]);
+            finalize_mul_cb(sd.mx[4], sd.e2, a.se, a.b3, sd.rs3, sd.e3, status);
+            sd.bn_e = sd.e3;
+            status_exps[2] = sd.e3;
+        }
+        __syncthreads();
+    }
+    // ---- stage 4: + bias             fxpmodel.py:928-933
+    if (a.bias) {
+        const int e3 = a.scale ? sd.e3 : sd.e2;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (act) {
+            const float fb = tofloat(a.bias[h], a.be);
+            const float f0 = tofloat(bn_chain<3>(a, sd, xlo, h), e3), f1 = tofloat(bn_chain<3>(a, sd, xhi, h), e3);
+            v[0] = fmaxf(fabsf(__fadd_rn(f0, fb)), fabsf(__fadd_rn(f1, fb)));
+            v[1] = fmaxf(fabsf(f0), fabsf(f1));
+            v[2] = fabsf(fb);
+        }
+        block_allmax<3>(v, red);
+        if (h == 0) {
+            uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
+            sd.mx[5] = m3[0]; sd.mx[6] = m3[1]; sd.mx[7] = m3[2];
+            sd.bn4 = finalize_add_cb(m3, e3, a.be, a.b4, status);
+            sd.bn_e = sd.bn4.eo;
+            status_exps[3] = sd.bn4.eo;
+        }
+        __syncthreads();
+    }
+    if (h == 0) { // publish (redo and the residual maxima slots of *d are written later in the layer)
+        d->bn1 = sd.bn1; d->rs2 = sd.rs2; d->e2 = sd.e2; d->rs3 = sd.rs3; d->e3 = sd.e3; d->bn4 = sd.bn4; d->bn_e = sd.bn_e;
+        for (int i = 0; i < 8; ++i) d->mx[i] = sd.mx[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lean BatchNorm chain for the MFMA path.  Preconditions (host-checked, the same as for the extremes
+// method): every BN operand <= 16 bit, exponents in [0,15]; the input is stored as int16 within its
+// nominal bits.  Under them this is bn_chain<> with the data-independent parts moved out of the element:
+//   * sat(v << 0, bits) == v for in-range v, so the "shift only if needed" selects disappear;
+//   * "post > 0 ? << : >>" is (v << l) >> r with one of l, r zero;
+//   * the per-channel operands (mean, bias) are shifted/saturated once per workgroup into LDS;
+//   * 16 x 16-bit products fit v_mul_i32_i24 (full rate), whose low 32 bits are the exact product;
+//   * change_cfg(t -> u) is a shift pair and one saturation at min(out_bits, u_bits).
+// ---------------------------------------------------------------------------------------------
+struct Bn16 {
+    const int32_t *m1, *isv, *sc, *b4; // LDS, (H) each
+    int32_t shx1, l1, r1, b1, xb;
+    int32_t rs2, b2;
+    int32_t has_sc, rs3, b3;
+    int32_t has_b, shx4, tb4, l4, r4, b4b;
+    int32_t cl, cr, cbits;
+};
+
+// builds the LDS tables (all threads) and returns the scalars; call before a __syncthreads()
+__device__ __forceinline__ Bn16 bn16_setup(const BnArgs &a, const LayerDyn &d, int32_t *lds, int H)
+{
+    Bn16 p;
+    int32_t *m1 = lds, *isv = lds + H, *sc = lds + 2 * H, *b4 = lds + 3 * H;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        m1[h] = sat(wshl(a.mm[h], d.bn1.shy), a.mb);
+        isv[h] = a.isv[h];
+        sc[h] = a.scale ? a.scale[h] : 0;
+        b4[h] = a.bias ? sat(wshl(a.bias[h], d.bn4.shy), a.bb) : 0;
+    }
+    p.m1 = m1; p.isv = isv; p.sc = sc; p.b4 = b4;
+    p.shx1 = d.bn1.shx; p.l1 = d.bn1.post > 0 ? d.bn1.post : 0; p.r1 = d.bn1.post < 0 ? -d.bn1.post : 0;
+    p.b1 = a.b1; p.xb = a.xb;
+    p.rs2 = d.rs2; p.b2 = a.b2;
+    p.has_sc = a.scale != nullptr; p.rs3 = d.rs3; p.b3 = a.b3;
+    p.has_b = a.bias != nullptr; p.shx4 = d.bn4.shx; p.tb4 = a.scale ? a.b3 : a.b2;
+    p.l4 = d.bn4.post > 0 ? d.bn4.post : 0; p.r4 = d.bn4.post < 0 ? -d.bn4.post : 0; p.b4b = a.b4;
+    const int de = a.ue - d.bn_e;
+    p.cl = de > 0 ? de : 0; p.cr = de < 0 ? -de : 0;
+    p.cbits = a.out_bits < a.ub ? a.out_bits : a.ub;
+    return p;
+}
+
+// four consecutive channels h0..h0+3: BatchNorm output t (pre_s5) and SSM input u
+__device__ __forceinline__ void bn16_x4(const Bn16 &p, const int32_t (&x)[4], int h0, int32_t (&t)[4], int32_t (&u)[4])
+{
+    const v4i m4 = *reinterpret_cast<const v4i *>(p.m1 + h0), i4 = *reinterpret_cast<const v4i *>(p.isv + h0);
+    v4i s4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0};
+    if (p.has_sc) s4 = *reinterpret_cast<const v4i *>(p.sc + h0);
+    if (p.has_b) b4 = *reinterpret_cast<const v4i *>(p.b4 + h0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int32_t v = sat(asr(wshl(wadd(sat(wshl(x[e], p.shx1), p.xb), m4[e]), p.l1), p.r1), p.b1);
+        v = sat(asr(__mul24(v, i4[e]), p.rs2), p.b2);
+        if (p.has_sc) v = sat(asr(__mul24(v, s4[e]), p.rs3), p.b3);
+        if (p.has_b) v = sat(asr(wshl(wadd(sat(wshl(v, p.shx4), p.tb4), b4[e]), p.l4), p.r4), p.b4b);
+        t[e] = v;
+        u[e] = sat(asr(wshl(v, p.cl), p.cr), p.cbits);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lean B projection.  LDS: [weights][cs128 Np][m1 H][isv H][scale H][bias H]
+// ---------------------------------------------------------------------------------------------
+struct BprojM2Args {
+    BnArgs bn;
+    const int16_t *x; // (N,H)
+    MfmaW w;
+    int32_t *bq;      // native stream
+    int16_t *u;       // (N,H) SSM input, for the C projection
+    int32_t *tr_bu_re, *tr_bu_im, *tr_pre_s5, *tr_u; // traces (TRACE instantiation only)
+    int64_t N;
+    int32_t L, TB, H, P;
+    int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
+};
+
+template <int KS, int NT, bool TRACE>
+__global__ __launch_bounds__(256, 2) void k_bproj_mfma2(BprojM2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    const int wbytes = a.w.Np * a.w.Kp, H = a.H;
+    int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes);
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles = (a.N + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    // this wave's first fragments are requested before the weights: one round of memory latency, not two
+    v4i raw[KS][2];
+    auto fetch = [&](int64_t tl) {
+        int64_t n = tl * 32 + r;
+        n = n < a.N ? n : a.N - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            raw[ks][0] = *reinterpret_cast<const v4i *>(a.x + n * H + 32 * ks + 16 * h);
+            raw[ks][1] = *reinterpret_cast<const v4i *>(a.x + n * H + 32 * ks + 16 * h + 8);
+        }
+    };
+    if (tile < tiles) fetch(tile);
+    const LayerDyn d = *a.bn.dyn;
+    stage_lds(smem, a.w.wt, wbytes);
+    stage_lds(cs, a.w.cs128, a.w.Np * 4);
+    const Bn16 bn = bn16_setup(a.bn, d, cs + a.w.Np, H);
+    __syncthreads();
+    const unsigned blk_words = (unsigned)a.P * 8u;
+    for (; tile < tiles; tile += stride) {
+        const int64_t n = tile * 32 + r;
+        v4i hi[KS], lo[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 32 * ks + 16 * h;
+            int32_t v[16];
+            unpack_i16(raw[ks][0], raw[ks][1], v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int32_t xin[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, t[4], u[4];
+                bn16_x4(bn, xin, k0 + 4 * q, t, u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (TRACE) {
+                        if (a.tr_pre_s5 && n < a.N) a.tr_pre_s5[n * H + k0 + 4 * q + e] = t[e];
+                        if (a.tr_u && n < a.N) a.tr_u[n * H + k0 + 4 * q + e] = u[e];
+                    }
+                    v[4 * q + e] = u[e];
+                }
+                if (n < a.N) *reinterpret_cast<v2i *>(a.u + n * H + k0 + 4 * q) = pack4_i16(u[0], u[1], u[2], u[3]);
+                S5_FENCE();
+            }
+            planes_from_i32(v, hi[ks], lo[ks]);
+            S5_FENCE();
+        }
+        if (tile + stride < tiles) fetch(tile + stride); // next tile's fragments fly during the MFMAs and the epilogue
+        v16i acc[NT];
+        mfma_2plane<KS, NT>(acc, smem, a.w.Kp, cs, 0, hi, lo);
+        S5_FENCE();
+        if (n < a.N) {
+            const int64_t b = n / a.L;
+            const int t = (int)(n - b * a.L);
+            // 2P = 32*NT channels, so P is a compile-time constant here and every store below is one per-lane
+            // base (frame, lane half) plus an immediate offset -- no per-element address arithmetic
+            constexpr int PC = 16 * NT;
+            int32_t *dst = a.bq + ((b * a.TB + (t >> 2)) * (int64_t)blk_words + (t & 3)) + 32 * h; // + (p*2 + c)*4, p = .. + 4h
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int c = (32 * ct >= PC) ? 1 : 0;
+                const int rs = c ? a.rs_im : a.rs_re, bits = c ? a.bim_bits : a.bre_bits, sh = c ? a.sh_im : a.sh_re;
+                const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int p0 = 32 * ct + 8 * g - c * PC; // + 4h is in dst
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int32_t bu = sat(asr(acc[ct][4 * g + e], rs), bits);
+                        dst[((p0 + e) * 2 + c) * 4] = asr(wshl(bu, lsh), rsh);
+                        if (TRACE) {
+                            if (!c && a.tr_bu_re) a.tr_bu_re[n * PC + p0 + 4 * h + e] = bu;
+                            if (c && a.tr_bu_im) a.tr_bu_im[n * PC + p0 + 4 * h + e] = bu;
+                        }
+                    }
+                }
+                S5_FENCE();
+            }
+        }
+    }
+}
+
+} // namespace s5

@@ -152,44 +152,59 @@ struct EncArgs {
 };
 
 template <int KS, int NT>
-__global__ __launch_bounds__(256, 2) void k_enc_mfma(EncArgs a)
+// one wave per SIMD: the 4-deep load ring (256 B per lane in flight) hides HBM latency by itself, and the
+// 9 k-steps of byte planes + accumulators do not fit 256 registers without spilling
+__global__ __launch_bounds__(256, 1) void k_enc_mfma(EncArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    constexpr int DEPTH = 4; // k-steps (64 bytes per lane each) in flight
     const int wbytes = a.w.Np * a.w.Kp;
     int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes), *be = cs + a.w.Np;
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles = (a.N + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    const uint64_t total_bytes = (uint64_t)a.N * a.K * 4;
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.x), 0,
+                                                  (int)(total_bytes > 0xfffffff0ull ? 0xfffffff0ull : total_bytes), 0x00020000);
+    // beyond the row end a load reads the next frame (multiplied by zero weights); beyond the tensor, 0
+    v4i buf[DEPTH][4];
+    auto issue = [&](unsigned row_off, int ks, v4i (&b)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            b[q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row_off + (unsigned)(128 * ks + 16 * q), 0, 0));
+    };
+    auto row_of = [&](int64_t tl) {
+        const int64_t n = tl * 32 + r;
+        return (unsigned)((n < a.N ? n : a.N - 1) * a.K * 4) + (unsigned)(16 * h * 4);
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < tiles) {
+        const unsigned ro = row_of(tile);
+#pragma unroll
+        for (int ks = 0; ks < DEPTH && ks < KS; ++ks) issue(ro, ks, buf[ks]);
+    }
     stage_lds(smem, a.w.wt, wbytes);
     stage_lds(cs, a.w.cs128, a.w.Np * 4);
     stage_lds(be, a.bias_eff, a.w.Np * 4);
     __syncthreads();
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + 31) / 32;
-    const uint64_t total_bytes = (uint64_t)a.N * a.K * 4;
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.x), 0,
-                                                  (int)(total_bytes > 0xfffffff0ull ? 0xfffffff0ull : total_bytes), 0x00020000);
     bool wide = false;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    for (; tile < tiles; tile += stride) {
         const int64_t n = tile * 32 + r;
+        const unsigned ro = row_of(tile);
+        const bool more = tile + stride < tiles;
+        const unsigned ro_next = more ? row_of(tile + stride) : ro;
         v4i hi[KS], lo[KS];
-        const unsigned row_off = (unsigned)((n < a.N ? n : a.N - 1) * a.K * 4) + (unsigned)(16 * h * 4);
-        // beyond the row end a load reads the next frame (multiplied by zero weights); beyond the tensor, 0
-        v4i buf[2][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            buf[0][q] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row_off + (unsigned)(16 * q), 0, 0));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    buf[(ks + 1) & 1][q] = __builtin_bit_cast(
-                        v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, row_off + (unsigned)(128 * (ks + 1) + 16 * q), 0, 0));
-            }
             int32_t v[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v4i t = buf[ks & 1][q];
+                const v4i t = buf[ks % DEPTH][q];
                 v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
             }
+            // refill the slot just consumed: the rest of this tile first, then the head of the next one
+            if (ks + DEPTH < KS) issue(ro, ks + DEPTH, buf[ks % DEPTH]);
+            else if (more) issue(ro_next, ks + DEPTH - KS, buf[ks % DEPTH]);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 if (a.conv) v[j] = chcfg(v[j], a.xb, a.xe, a.inp_bits, a.inp_exp);
@@ -320,7 +335,8 @@ __global__ __launch_bounds__(256, 2) void k_bproj_mfma(BprojMArgs a)
 // ---------------------------------------------------------------------------------------------
 struct CprojMArgs {
     BnArgs bn;
-    const int16_t *x;    // (N,H) layer input (for u)
+    const int16_t *x;    // (N,H): the SSM input u (have_u) or the layer input from which u is recomputed
+    int32_t have_u;
     const int32_t *xs;   // native raw states
     MfmaW w_re, w_im;    // H channels each, K = P
     const int32_t *D;    // (Np)
@@ -338,11 +354,29 @@ template <int KS, int NT>
 __global__ __launch_bounds__(256, 2) void k_cproj_mfma(CprojMArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    constexpr int P = 32 * KS;         // K of this projection is the state count
+    constexpr int ITER = 8 * P / 64;   // 32-byte (state, 4 steps, re+im) chunks per lane and tile
+    constexpr int BATCH = 8;           // chunks in flight per lane
     const int wbytes = a.w_re.Np * a.w_re.Kp, Np = a.w_re.Np;
     int8_t *Wre = smem, *Wim = smem + wbytes;
     int32_t *csr = reinterpret_cast<int32_t *>(smem + 2 * wbytes), *csi = csr + Np, *Dl = csi + Np;
-    const int row_bytes = 2 * a.P * 2 + 16; // [comp][state] int16 + pad (odd number of 16-byte slots)
+    constexpr int row_bytes = 2 * P * 2 + 16; // [comp][state] int16 + pad (odd number of 16-byte slots)
     int8_t *tile = reinterpret_cast<int8_t *>(Dl + Np) + (threadIdx.x >> 6) * 32 * row_bytes;
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles = (a.N + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile_i = (int64_t)blockIdx.x * 4 + wave;
+    // epilogue operand (u or the layer input), requested with the tile's first loads
+    v2i uq[NT][4];
+    auto fetch_u = [&](int64_t tl) {
+        int64_t n = tl * 32 + r;
+        n = n < a.N ? n : a.N - 1;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) uq[ct][g] = *reinterpret_cast<const v2i *>(a.x + n * a.H + 32 * ct + 8 * g + 4 * h);
+    };
+    if (tile_i < tiles) fetch_u(tile_i);
     stage_lds(Wre, a.w_re.wt, wbytes);
     stage_lds(Wim, a.w_im.wt, wbytes);
     stage_lds(csr, a.w_re.cs128, Np * 4);
@@ -350,29 +384,39 @@ __global__ __launch_bounds__(256, 2) void k_cproj_mfma(CprojMArgs a)
     stage_lds(Dl, a.D, Np * 4);
     __syncthreads();
     const LayerDyn d = *a.bn.dyn;
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + 31) / 32;
     bool bad = false;
-    for (int64_t tile_i = (int64_t)blockIdx.x * 4 + wave; tile_i < tiles; tile_i += (int64_t)gridDim.x * 4) {
+    for (; tile_i < tiles; tile_i += stride) {
         const int64_t n0 = tile_i * 32;
-        // ---- stage: 8 groups of 4 frames x P states; one (state, 4 steps, re+im) chunk of 32 bytes per lane-iteration
-        for (int q = l; q < 8 * a.P; q += 64) {
-            const int grp = q / a.P, p = q - grp * a.P;
-            const int64_t nf = n0 + 4 * grp; // first frame of the group (L % 4 == 0: a group never straddles sequences)
-            if (nf < a.N) {
+        // ---- stage: 8 groups of 4 frames x P states, coalesced 32-byte chunks, BATCH of them in flight per lane
+#pragma unroll
+        for (int bt = 0; bt < ITER / BATCH; ++bt) {
+            v4i cre[BATCH], cim[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int q = l + 64 * (bt * BATCH + i);
+                const int grp = q / P, p = q % P;
+                int64_t nf = n0 + 4 * grp; // first frame of the group (L % 4 == 0: a group never straddles sequences)
+                nf = nf < a.N ? nf : a.N - 4;
                 const int64_t b = nf / a.L;
                 const int t = (int)(nf - b * a.L);
-                const int32_t *src = a.xs + native_word(b, t, p, 0, a.TB, a.P);
-                const v4i re = *reinterpret_cast<const v4i *>(src);
-                const v4i im = *reinterpret_cast<const v4i *>(src + 4);
+                const int32_t *src = a.xs + native_word(b, t, p, 0, a.TB, P);
+                cre[i] = *reinterpret_cast<const v4i *>(src);
+                cim[i] = *reinterpret_cast<const v4i *>(src + 4);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int32_t xr = re[j], xi = im[j];
-                    bad |= (xr > a.xmax) | (xr < -a.xmax) | (xi > a.xmax) | (xi < -a.xmax);
-                    crelu(xr, xi);
-                    int8_t *row = tile + (4 * grp + j) * row_bytes;
-                    *reinterpret_cast<int16_t *>(row + 2 * p) = (int16_t)xr;
-                    *reinterpret_cast<int16_t *>(row + 2 * (a.P + p)) = (int16_t)xi;
+            for (int i = 0; i < BATCH; ++i) {
+                const int q = l + 64 * (bt * BATCH + i);
+                const int grp = q / P, p = q % P;
+                if (n0 + 4 * grp < a.N) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int32_t xr = cre[i][j], xi = cim[i][j];
+                        bad |= (xr > a.xmax) | (xr < -a.xmax) | (xi > a.xmax) | (xi < -a.xmax);
+                        crelu(xr, xi);
+                        int8_t *row = tile + (4 * grp + j) * row_bytes;
+                        *reinterpret_cast<int16_t *>(row + 2 * p) = (int16_t)xr;
+                        *reinterpret_cast<int16_t *>(row + 2 * (P + p)) = (int16_t)xi;
+                    }
                 }
             }
         }
@@ -385,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void k_cproj_mfma(CprojMArgs a)
         for (int ks = 0; ks < KS; ++ks) {
             const int k0 = 32 * ks + 16 * h;
             planes_from_i16(*reinterpret_cast<const v4i *>(row + 2 * k0), *reinterpret_cast<const v4i *>(row + 2 * k0 + 16), hr[ks], lr[ks]);
-            planes_from_i16(*reinterpret_cast<const v4i *>(row + 2 * (a.P + k0)), *reinterpret_cast<const v4i *>(row + 2 * (a.P + k0) + 16), hm[ks], lm[ks]);
+            planes_from_i16(*reinterpret_cast<const v4i *>(row + 2 * (P + k0)), *reinterpret_cast<const v4i *>(row + 2 * (P + k0) + 16), hm[ks], lm[ks]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ... and its reads before the next tile's writes
         v16i are[NT], aim[NT];
@@ -401,14 +445,15 @@ __global__ __launch_bounds__(256, 2) void k_cproj_mfma(CprojMArgs a)
                     if (ch < a.H) {
                         const v4i Dv = *reinterpret_cast<const v4i *>(Dl + ch);
                         int32_t hv[4], o[4];
-                        unpack4_i16(*reinterpret_cast<const v2i *>(a.x + n * a.H + ch), hv);
+                        unpack4_i16(uq[ct][g], hv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int32_t cr = sat(asr(are[ct][4 * g + e], a.rs_re), a.y_bits);
                             const int32_t ci = sat(asr(aim[ct][4 * g + e], a.rs_im), a.y_bits);
                             const int32_t cx = sat(wadd(cr, wmul(ci, -1)), a.y_bits);
                             const int32_t cx2 = wmul(cx, 2); // not clipped, fxpmodel.py:765-767
-                            const int32_t u = bn_chain<5>(a.bn, d, hv[e], ch + e);
+                            // x points at the stored SSM input u when have_u, else at the layer input (chain recomputed)
+                            const int32_t u = a.have_u ? hv[e] : bn_chain<5>(a.bn, d, hv[e], ch + e);
                             const int32_t du = sat(asr(wmul(Dv[e], u), a.rs_d), a.y_bits);
                             const int32_t y = sat(wadd(cx2, du), a.y_bits);
                             if (a.tr_ys) a.tr_ys[n * a.H + ch + e] = y;
@@ -420,6 +465,8 @@ __global__ __launch_bounds__(256, 2) void k_cproj_mfma(CprojMArgs a)
                 S5_FENCE();
             }
         }
+        if (tile_i + stride < tiles) fetch_u(tile_i + stride);
+        __builtin_amdgcn_wave_barrier();
     }
     if (__any(bad) && l == 0) {
         atomicExch(&a.dynw->redo, 1);
@@ -454,27 +501,41 @@ __global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int wbytes = a.w.Np * a.w.Kp;
     int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes), *be = cs + a.w.Np, *lut = be + a.w.Np;
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles = (a.N + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    // Every global load of a tile -- MFMA fragments and the epilogue's x1 / skip operands -- is issued in one
+    // go (for the first tile even before the weights are staged), so a tile costs one round of memory latency.
+    v4i raw[KS][2];
+    v2i xq[NT][4], sq[NT][4];
+    auto fetch = [&](int64_t tl) {
+        int64_t n = tl * 32 + r;
+        n = n < a.N ? n : a.N - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            raw[ks][0] = *reinterpret_cast<const v4i *>(a.x1 + n * a.H + 32 * ks + 16 * h);
+            raw[ks][1] = *reinterpret_cast<const v4i *>(a.x1 + n * a.H + 32 * ks + 16 * h + 8);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xq[ct][g] = *reinterpret_cast<const v2i *>(a.x1 + n * a.H + 32 * ct + 8 * g + 4 * h);
+                sq[ct][g] = *reinterpret_cast<const v2i *>(a.skip + n * a.H + 32 * ct + 8 * g + 4 * h);
+            }
+    };
+    if (tile < tiles) fetch(tile);
     if (threadIdx.x < 8) lut[threadIdx.x] = a.lut[threadIdx.x];
     stage_lds(smem, a.w.wt, wbytes);
     stage_lds(cs, a.w.cs128, a.w.Np * 4);
     stage_lds(be, a.bias_eff, a.w.Np * 4);
     __syncthreads();
     const int skip_e = a.skip_e.get();
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + 31) / 32;
     float mx[3] = {0.f, 0.f, 0.f};
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    for (; tile < tiles; tile += stride) {
         const int64_t n = tile * 32 + r;
-        const int64_t nn = n < a.N ? n : a.N - 1;
         v4i hi[KS], lo[KS];
-        v4i raw[KS][2];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k0 = 32 * ks + 16 * h;
-            raw[ks][0] = *reinterpret_cast<const v4i *>(a.x1 + nn * a.H + k0);
-            raw[ks][1] = *reinterpret_cast<const v4i *>(a.x1 + nn * a.H + k0 + 8);
-        }
-        S5_FENCE();
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (a.conv) {
@@ -500,8 +561,8 @@ __global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
                     if (ch < a.H) {
                         const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
                         int32_t xv[4], sv[4], o[4];
-                        unpack4_i16(*reinterpret_cast<const v2i *>(a.x1 + n * a.H + ch), xv);
-                        unpack4_i16(*reinterpret_cast<const v2i *>(a.skip + n * a.H + ch), sv);
+                        unpack4_i16(xq[ct][g], xv);
+                        unpack4_i16(sq[ct][g], sv);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             int32_t gq = sat(asr(acc[ct][4 * g + e], a.rs), a.out_bits);
@@ -525,6 +586,7 @@ __global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
                 S5_FENCE();
             }
         }
+        if (tile + stride < tiles) fetch(tile + stride);
     }
     block_max_atomic<3>(mx, a.dynw->mx + 8);
 }

@@ -4,7 +4,7 @@
 // caller's stream.  No device allocation, no synchronisation, no global mutable state.
 #include "../../include/s5fxp.h"
 #include "s5fxp_kernels.hpp"
-#include "mfma_proj.hpp"
+#include "mfma_bn.hpp"
 
 #include <algorithm>
 #include <cstdlib>

@@ -125,7 +125,7 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
 }
 
 struct FastWs {
-    size_t hA, hB, x1, z, bq, xs, dyn, total;
+    size_t hA, hB, x1, z, u, bq, xs, dyn, ext, dyn_bytes, total;
     int TB;
 };
 
@@ -142,9 +142,13 @@ FastWs fast_ws(const s5fxp_model *m, int B, int L)
     w.hB = off; off += nh;
     w.x1 = off; off += nh;
     w.z = off; off += nh;
+    w.u = off; off += nh;
     w.bq = off; off += ns;
     w.xs = off; off += ns;
+    // per-layer device state and per-channel extremes: contiguous, zeroed by one memset per forward
     w.dyn = off; off += al(sizeof(LayerDyn) * (size_t)m->n_layers);
+    w.ext = off; off += al(sizeof(float) * 2 * (size_t)m->H * (size_t)m->n_layers);
+    w.dyn_bytes = off - w.dyn;
     w.total = off;
     return w;
 }
@@ -183,7 +187,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const unsigned grid = mfma_grid(N);
     int rc;
     if ((rc = hip_rc(hipMemsetAsync(status, 0, sizeof(int32_t) * S5FXP_STATUS_WORDS, st)))) return rc;
-    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)m->n_layers, st)))) return rc;
+    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, w.dyn_bytes, st)))) return rc;
+    // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
+    // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
+    bool bn_ext = m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
+    for (int li = 0; li < m->n_layers; ++li) {
+        const s5fxp_norm_desc &n = m->layers[li].nd;
+        auto ok = [](int bits, int e) { return bits <= 16 && e >= 0 && e <= 15; };
+        bn_ext = bn_ext && ok(n.mean_bits, n.mean_exp) && ok(n.invsq_var_bits, n.invsq_var_exp) &&
+                 (!m->layers[li].scale || ok(n.scale_bits, n.scale_exp)) && (!m->layers[li].nbias || ok(n.bias_bits, n.bias_exp)) &&
+                 m->layers[li].res_bits <= 16;
+    }
 
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
     // ---- encoder + ReLU
@@ -225,6 +239,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         auto hook = [&](int slot, int n) -> int {
             return allreduce ? allreduce(allreduce_ctx, reinterpret_cast<float *>(d->mx + slot), n, (void *)st) : 0;
         };
+        if (bn_ext) {
+            float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H;
+            hipLaunchKernelGGL(k_minmax16, dim3(512), dim3(256), 0, st, (const int16_t *)h, N, H, ext);
+            // mode A: the extremes (positive floats) are what the ranks exchange -- one MAX over 2H values
+            if (allreduce && allreduce(allreduce_ctx, ext, 2 * H, (void *)st)) return S5FXP_EHIP;
+            hipLaunchKernelGGL(k_bn_finalize_mm, dim3(1), dim3(256), 0, st, bn, (const float *)ext, H, d, status, st_exps);
+        } else {
         hipLaunchKernelGGL(k_bn_reduce16<1>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
         if (hook(0, 3)) return S5FXP_EHIP;
         hipLaunchKernelGGL(k_bn_finalize<1>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
@@ -241,20 +262,26 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             if (hook(5, 3)) return S5FXP_EHIP;
             hipLaunchKernelGGL(k_bn_finalize<4>, dim3(1), dim3(64), 0, st, bn, d, status, st_exps);
         }
+        }
 
-        // ---- B projection -> scan-native stream
+        // ---- B projection -> scan-native stream (+ u for the C projection)
         const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
         {
-            BprojMArgs a{};
-            a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq);
+            BprojM2Args a{};
+            a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
             a.tr_bu_re = tr ? tr->Bu_re : nullptr; a.tr_bu_im = tr ? tr->Bu_im : nullptr;
             a.tr_pre_s5 = tr ? tr->pre_s5 : nullptr; a.tr_u = tr ? tr->u : nullptr;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
-            const size_t smem = (size_t)a.w.Np * a.w.Kp + (size_t)a.w.Np * 4; // weights + cs128
-            if (big) launch_smem(k_bproj_mfma<6, 8>, grid, smem, st, a);
-            else launch_smem(k_bproj_mfma<3, 4>, grid, smem, st, a);
+            const size_t smem = (size_t)a.w.Np * a.w.Kp + (size_t)a.w.Np * 4 + 4 * (size_t)H * 4; // weights + cs128 + BN params
+            if (tr) {
+                if (big) launch_smem(k_bproj_mfma2<6, 8, true>, grid, smem, st, a);
+                else launch_smem(k_bproj_mfma2<3, 4, true>, grid, smem, st, a);
+            } else {
+                if (big) launch_smem(k_bproj_mfma2<6, 8, false>, grid, smem, st, a);
+                else launch_smem(k_bproj_mfma2<3, 4, false>, grid, smem, st, a);
+            }
         }
         // ---- recurrence
         ScanArgs sl{};
@@ -277,7 +304,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // ---- C projection + D*u + ReLU (MFMA, range check); exact 32-bit re-run if the check fails
         {
             CprojMArgs a{};
-            a.bn = bn; a.x = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.D = fl.Dpad;
+            a.bn = bn; a.x = I16(w.u); a.have_u = 1; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.D = fl.Dpad;
             a.x1 = I16(w.x1); a.tr_ys = tr ? tr->ys : nullptr; a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
             a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.xmax = xmax; a.dynw = d; a.status = status;
