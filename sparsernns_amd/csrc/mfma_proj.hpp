@@ -493,11 +493,14 @@ struct GateMArgs {
     int32_t l_bits, l_exp, r_bits, r_exp, res_bits, res_exp, rs_gate;
     DynExp skip_e;
     LayerDyn *dynw;
+    const int32_t *run_if; // exact re-run: do the work only when *run_if != 0 (nullptr: always)
+    int32_t mx_slot;       // first of the three LayerDyn::mx slots that receive the maxima
 };
 
 template <int KS, int NT>
 __global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
 {
+    if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     const int wbytes = a.w.Np * a.w.Kp;
     int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes), *be = cs + a.w.Np, *lut = be + a.w.Np;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
         }
         if (tile + stride < tiles) fetch(tile + stride);
     }
-    block_max_atomic<3>(mx, a.dynw->mx + 8);
+    block_max_atomic<3>(mx, a.dynw->mx + a.mx_slot);
 }
 
 // ---------------------------------------------------------------------------------------------

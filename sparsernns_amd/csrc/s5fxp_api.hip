@@ -4,7 +4,7 @@
 // caller's stream.  No device allocation, no synchronisation, no global mutable state.
 #include "../../include/s5fxp.h"
 #include "s5fxp_kernels.hpp"
-#include "mfma_bn.hpp"
+#include "mfma_fused.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -650,7 +650,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             if (tr && tr->post_GLU) hipMemcpyAsync(tr->post_GLU, a.z, (size_t)NH * 4, hipMemcpyDeviceToDevice, st);
         }
         if (hook(8, 3)) return S5FXP_EHIP;
-        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps);
+        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps, 8);
         hipLaunchKernelGGL(k_resid, dim3(ew_grid(NH)), dim3(256), 0, st, (const int32_t *)I(w.z), (const int32_t *)h, hn,
                            tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
         int32_t *sw = h; h = hn; hn = sw;

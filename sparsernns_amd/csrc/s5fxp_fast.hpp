@@ -11,6 +11,7 @@ struct MfmaWDev {
 
 struct FastLayer {
     MfmaWDev bproj, cre, cim, out2;
+    MfmaWDev out2p; // out2 with the k-order of every 32-block permuted to the accumulator layout (mfma_fused.hpp)
     const int32_t *Dpad = nullptr; // [Np]
 };
 
@@ -66,8 +67,10 @@ bool fast_eligible(const s5fxp_model_desc *d)
 }
 
 // get(k, ch) -> weight; result rows are channels, padded and strided for conflict-free 16-byte LDS reads
+// kperm: within each block of 32 k, position 16*h + 4*g + e holds the weight of k = 8*g + 4*h + e, the order
+// in which a lane of the previous MFMA's accumulator tile holds its channels
 template <class Get>
-void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o)
+void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o, bool kperm = false)
 {
     const int Kpad = (K + 31) / 32 * 32;
     const int Kp = ((Kpad / 16) % 2 == 0) ? Kpad + 16 : Kpad;
@@ -78,7 +81,12 @@ void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o)
         uint32_t sum = 0;
         for (int k = 0; k < K; ++k) {
             const int32_t v = get(k, ch);
-            wt[(size_t)ch * Kp + k] = (int8_t)v;
+            int pos = k;
+            if (kperm) {
+                const int blk = k & ~31, kk = k & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
+                pos = blk + 16 * hh + 4 * g + e;
+            }
+            wt[(size_t)ch * Kp + pos] = (int8_t)v;
             sum += (uint32_t)v;
         }
         cs[ch] = (int32_t)(sum * 128u);
@@ -115,6 +123,7 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
         pack_mfma(p, [&](int k, int ch) { return s.C_im[(size_t)ch * P + k]; }, P, H, o.cim);
         pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2);
         pack_bias_eff(p, l.out2, o.out2.w.Np, o.out2);
+        pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2p, true);
         std::vector<int32_t> Dp(o.cre.w.Np, 0);
         for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
         o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
@@ -301,16 +310,59 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
         }
         if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
-        // ---- C projection + D*u + ReLU (MFMA, range check); exact 32-bit re-run if the check fails
+        // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
+        GateMArgs ga{};
+        bool fused = false;
         {
-            CprojMArgs a{};
-            a.bn = bn; a.x = I16(w.u); a.have_u = 1; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.D = fl.Dpad;
-            a.x1 = I16(w.x1); a.tr_ys = tr ? tr->ys : nullptr; a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
+            const DenseDev &o = l.out2;
+            ga.x1 = I16(w.x1); ga.skip = h; ga.z = I16(w.z); ga.w = fl.out2.w; ga.bias_eff = fl.out2.bias_eff;
+            ga.tr_out2 = tr ? tr->out2 : nullptr; ga.tr_sig = tr ? tr->out2_sigmoid : nullptr;
+            ga.tr_z = tr ? tr->post_GLU : nullptr;
+            ga.N = N; ga.H = H; ga.y_bits = s.y_bits; ga.y_exp = s.y_exp;
+            ga.conv = (s.y_bits > o.inp_bits || s.y_exp > o.inp_exp) ? 1 : 0;
+            ga.inp_bits = o.inp_bits; ga.inp_exp = o.inp_exp;
+            ga.rs = (ga.conv ? o.inp_exp : s.y_exp) + o.w_exp - o.out_exp;
+            if (!shift_ok(ga.rs)) return S5FXP_ENEGSHIFT;
+            ga.out_bits = o.out_bits; ga.out_exp = o.out_exp; ga.sig_x = l.sig_x; ga.sig_y = l.sig_y;
+            std::memcpy(ga.lut, l.lut, sizeof(ga.lut));
+            ga.l_bits = l.l_bits; ga.l_exp = l.l_exp; ga.r_bits = l.r_bits; ga.r_exp = l.r_exp; ga.res_bits = l.res_bits;
+            ga.res_exp = l.res_exp; ga.rs_gate = l.l_exp + l.r_exp - l.res_exp; ga.skip_e = he; ga.dynw = d;
+        }
+        {
+            CGateArgs a{};
+            a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2p.w;
+            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z);
+            a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
+            a.N = N; a.L = L; a.TB = w.TB; a.H = H;
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
-            a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.xmax = xmax; a.dynw = d; a.status = status;
-            const size_t smem = 2 * (size_t)a.w_re.Np * a.w_re.Kp + 3 * (size_t)a.w_re.Np * 4 + 4 * 32 * (size_t)(4 * P + 16);
-            if (big) launch_smem(k_cproj_mfma<4, 6>, grid, smem, st, a);
-            else launch_smem(k_cproj_mfma<2, 3>, grid, smem, st, a);
+            a.rs_d = s.D_exp + s.u_exp - s.y_exp; a.y_bits = s.y_bits; a.y_exp = s.y_exp; a.xmax = xmax;
+            a.conv = ga.conv; a.inp_bits = ga.inp_bits; a.inp_exp = ga.inp_exp; a.rs_o2 = ga.rs; a.out_bits = ga.out_bits;
+            a.out_exp = ga.out_exp; a.sig_x = l.sig_x; a.sig_y = l.sig_y;
+            std::memcpy(a.lut, l.lut, sizeof(a.lut));
+            a.l_bits = l.l_bits; a.l_exp = l.l_exp; a.r_bits = l.r_bits; a.r_exp = l.r_exp; a.res_bits = l.res_bits;
+            a.res_exp = l.res_exp; a.rs_gate = ga.rs_gate; a.skip_e = he; a.dynw = d; a.status = status;
+            const size_t np = (size_t)a.w_re.Np;
+            const size_t smem = 2 * np * a.w_re.Kp + (size_t)a.w_o2.Np * a.w_o2.Kp + 5 * np * 4 + 32 + 4 * 32 * (size_t)(4 * P + 16);
+            fused = smem <= 160 * 1024; // the dim_scale 1.0 tile set does not fit one CU's LDS: two kernels there
+            if (fused) {
+                if (tr) {
+                    if (big) launch_smem(k_cgate_mfma<4, 6, true>, grid, smem, st, a);
+                    else launch_smem(k_cgate_mfma<2, 3, true>, grid, smem, st, a);
+                } else {
+                    if (big) launch_smem(k_cgate_mfma<4, 6, false>, grid, smem, st, a);
+                    else launch_smem(k_cgate_mfma<2, 3, false>, grid, smem, st, a);
+                }
+            } else {
+                CprojMArgs c{};
+                c.bn = bn; c.x = I16(w.u); c.have_u = 1; c.xs = I32(w.xs); c.w_re = fl.cre.w; c.w_im = fl.cim.w; c.D = fl.Dpad;
+                c.x1 = I16(w.x1); c.tr_ys = tr ? tr->ys : nullptr; c.N = N; c.L = L; c.TB = w.TB; c.H = H; c.P = P;
+                c.rs_re = a.rs_re; c.rs_im = a.rs_im; c.rs_d = a.rs_d; c.y_bits = s.y_bits; c.xmax = xmax; c.dynw = d;
+                c.status = status;
+                const size_t smc = 2 * np * c.w_re.Kp + 3 * np * 4 + 4 * 32 * (size_t)(4 * P + 16);
+                if (big) launch_smem(k_cproj_mfma<4, 6>, grid, smc, st, c);
+                else launch_smem(k_cproj_mfma<2, 3>, grid, smc, st, c);
+            }
+            // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo)
             if (l.quad_ok) {
                 sl.run_if = &d->redo;
                 hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
@@ -322,32 +374,24 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             g.xmax = xmax; g.dynw = d; g.status = status;
             const unsigned tiles = (unsigned)((N + TN - 1) / TN);
             S5_DISPATCH_MW_C(g.mw, false, 1, int16_t, tiles, st, g);
+            // fused: this gate kernel is the re-run's (maxima in slots 11..13); unfused: it is THE gate kernel and
+            // runs after x1 is final either way
+            ga.run_if = fused ? &d->redo : nullptr;
+            ga.mx_slot = fused ? 11 : 8;
+            const size_t smem2 = (size_t)ga.w.Np * ga.w.Kp + 2 * (size_t)ga.w.Np * 4 + 32;
+            if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem2, st, ga);
+            else launch_smem(k_out2gate_mfma<3, 3>, grid, smem2, st, ga);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);
         }
-        // ---- out2 + sigmoid + gate + residual maxima
-        {
-            const DenseDev &o = l.out2;
-            GateMArgs a{};
-            a.x1 = I16(w.x1); a.skip = h; a.z = I16(w.z); a.w = fl.out2.w; a.bias_eff = fl.out2.bias_eff;
-            a.tr_out2 = tr ? tr->out2 : nullptr; a.tr_sig = tr ? tr->out2_sigmoid : nullptr;
-            a.tr_z = tr ? tr->post_GLU : nullptr;
-            a.N = N; a.H = H; a.y_bits = s.y_bits; a.y_exp = s.y_exp;
-            a.conv = (s.y_bits > o.inp_bits || s.y_exp > o.inp_exp) ? 1 : 0;
-            a.inp_bits = o.inp_bits; a.inp_exp = o.inp_exp;
-            a.rs = (a.conv ? o.inp_exp : s.y_exp) + o.w_exp - o.out_exp;
-            if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
-            a.out_bits = o.out_bits; a.out_exp = o.out_exp; a.sig_x = l.sig_x; a.sig_y = l.sig_y;
-            std::memcpy(a.lut, l.lut, sizeof(a.lut));
-            a.l_bits = l.l_bits; a.l_exp = l.l_exp; a.r_bits = l.r_bits; a.r_exp = l.r_exp; a.res_bits = l.res_bits;
-            a.res_exp = l.res_exp; a.rs_gate = l.l_exp + l.r_exp - l.res_exp; a.skip_e = he; a.dynw = d;
-            const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4 + 32; // + lut
-            if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem, st, a);
-            else launch_smem(k_out2gate_mfma<3, 3>, grid, smem, st, a);
+        if (allreduce) {
+            // ranks may differ in `redo`: move the valid maxima to slots 8..10 before they are exchanged
+            if (fused) hipLaunchKernelGGL(k_select_maxima, dim3(1), dim3(64), 0, st, d);
+            if (hook(8, 3)) return S5FXP_EHIP;
         }
-        if (hook(8, 3)) return S5FXP_EHIP;
-        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps);
+        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps,
+                           (fused && !allreduce) ? 11 : 8);
         hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z), (const int16_t *)h,
                            hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
         int16_t *sw = h; h = hn; hn = sw;

@@ -181,10 +181,12 @@ __global__ void k_bn_finalize(BnArgs a, LayerDyn *d, int32_t *status, int32_t *s
 }
 
 __global__ void k_res_finalize(LayerDyn *d, int res_exp, DynExp skip_e, int res_bits, int32_t *status,
-                               int32_t *status_exps)
+                               int32_t *status_exps, int redo_slot)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    d->res = finalize_add_cb(d->mx + 8, res_exp, skip_e.get(), res_bits, status);
+    // MFMA path: the exact re-run of a layer (redo) leaves its maxima in slots 11..13 (redo_slot), the fused
+    // fast kernel's are in 8..10; the generic path has a single gate kernel and passes redo_slot = 8
+    d->res = finalize_add_cb(d->mx + (d->redo ? redo_slot : 8), res_exp, skip_e.get(), res_bits, status);
     status_exps[4] = d->res.eo;
 }
 
