@@ -198,7 +198,7 @@ typedef struct {
     s5fxp_allreduce_max_fn allreduce; /* NULL: per-shard exponents */
     void *allreduce_ctx;
     /* Measurement only: 2*n_layers hipEvent_t handles (or NULL); events [2l] / [2l+1] are recorded on
-     * `stream` immediately before / after layer l's recurrence kernel(s). */
+     * `stream` immediately before / after layer l's recurrence kernel(s). NULL entries are skipped. */
     void **scan_events;
 } s5fxp_forward_opts;
 

@@ -6,7 +6,7 @@
 //     wrap while all operands are <= 16 bit with exponents in [0,15], which the host checks), int32->float32
 //     and float32 add/mul by a constant are monotone as well, and |.| of a monotone function peaks at an end
 //     point.  So max over the tensor = max over channels of the two end points min_h(x), max_h(x): ONE pass
-//     over the tensor (k_minmax16) and one single-workgroup kernel (k_bn_finalize_mm) replace four reduction
+//     over the tensor (k_resid_minmax16, fused with the previous layer's residual add) and one single-workgroup kernel (k_bn_finalize_mm) replace four reduction
 //     passes.  The results are identical by construction; tests compare against the oracle's full reductions.
 //
 // (2) k_bproj_mfma2: same arithmetic as k_bproj_mfma, but BatchNorm parameters come from LDS, the chain runs
@@ -24,37 +24,86 @@ namespace s5 {
 // ---------------------------------------------------------------------------------------------
 constexpr float EXT_BIAS = 65536.f;
 
-// block = 256 threads = G channel-groups (4 channels each) x R frame lanes; G = H/4 (24 or 48)
-__global__ __launch_bounds__(256) void k_minmax16(const int16_t *__restrict__ x, int64_t N, int H, float *ext)
+__device__ __forceinline__ void unpack8_i16(const v4i &w, int32_t (&v)[8])
 {
-    __shared__ int32_t smin[256 * 4], smax[256 * 4];
-    const int G = H >> 2, R = 256 / G;
-    const int g = threadIdx.x % G, rl = threadIdx.x / G;
-    int32_t lo[4] = {32767, 32767, 32767, 32767}, hi[4] = {-32768, -32768, -32768, -32768};
-    if (rl < R) {
-        for (int64_t n = (int64_t)blockIdx.x * R + rl; n < N; n += (int64_t)gridDim.x * R) {
-            int32_t v[4];
-            unpack4_i16(*reinterpret_cast<const v2i *>(x + n * H + 4 * g), v);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lo[e] = v[e] < lo[e] ? v[e] : lo[e];
-                hi[e] = v[e] > hi[e] ? v[e] : hi[e];
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = (int32_t)(int16_t)(w[i] & 0xffff);
+        v[2 * i + 1] = w[i] >> 16;
+    }
+}
+
+// Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
+// layer's BatchNorm operand).  RESID=false: extremes of z only (the encoder output ahead of layer 0).
+// block = 256 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes; four frames in flight
+// per thread.  ext == nullptr: no extremes wanted (last layer).
+template <bool RESID>
+__global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
+                                                        int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
+                                                        int res_bits, int skip_bits, const LayerDyn *dyn, float *ext)
+{
+    __shared__ int32_t smin[256 * 8], smax[256 * 8];
+    const int G = H >> 3, R = 256 / G;
+    const int g = threadIdx.x % G, rl = threadIdx.x / G;
+    AddCb p{};
+    if constexpr (RESID) p = dyn->res;
+    int32_t lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lo[e] = 32767;
+        hi[e] = -32768;
+    }
+    if (rl < R) {
+        const int64_t stride = (int64_t)gridDim.x * R;
+        for (int64_t n0 = (int64_t)blockIdx.x * R + rl; n0 < N; n0 += 4 * stride) {
+            v4i zq[4], sq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t n = n0 + k * stride;
+                if (n < N) {
+                    zq[k] = *reinterpret_cast<const v4i *>(z + n * H + 8 * g);
+                    if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t n = n0 + k * stride;
+                if (n < N) {
+                    int32_t v[8], s[8];
+                    unpack8_i16(zq[k], v);
+                    if constexpr (RESID) {
+                        unpack8_i16(sq[k], s);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
+                            if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
+                            v[e] = rr < 0 ? 0 : rr;
+                        }
+                        const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
+                        *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        lo[e] = v[e] < lo[e] ? v[e] : lo[e];
+                        hi[e] = v[e] > hi[e] ? v[e] : hi[e];
+                    }
+                }
             }
         }
     }
+    if (!ext) return;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        smin[threadIdx.x * 4 + e] = lo[e];
-        smax[threadIdx.x * 4 + e] = hi[e];
+    for (int e = 0; e < 8; ++e) {
+        smin[threadIdx.x * 8 + e] = lo[e];
+        smax[threadIdx.x * 8 + e] = hi[e];
     }
     __syncthreads();
     if (threadIdx.x < H) { // one thread per channel folds the R frame lanes
-        const int c = threadIdx.x, cg = c >> 2, ce = c & 3;
+        const int c = threadIdx.x;
         int32_t a = 32767, b = -32768;
         for (int r = 0; r < R; ++r) {
-            const int t = r * G + cg;
-            a = min(a, smin[t * 4 + ce]);
-            b = max(b, smax[t * 4 + ce]);
+            a = min(a, smin[r * G * 8 + c]);
+            b = max(b, smax[r * G * 8 + c]);
         }
         atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)a));
         atomicMax(reinterpret_cast<uint32_t *>(ext) + H + c, __float_as_uint(EXT_BIAS + (float)b));

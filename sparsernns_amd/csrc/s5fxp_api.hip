@@ -597,7 +597,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = (1 << 23) - 1; // the 24-bit C projection's own limit
         const bool quad = l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC);
-        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
+        if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
         if (quad) {
             ScanQuadArgs q{};
             q.bq = I(w.bq); q.xs = I(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
@@ -608,7 +608,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             sl.run_if = nullptr;
             hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
         }
-        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
+        if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
         // ---- C projection + D*u + ReLU: pass 0 (24-bit multiplies, range check), then the exact re-run
         {
             CprojArgs a{};

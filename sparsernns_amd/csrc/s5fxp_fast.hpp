@@ -250,7 +250,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         };
         if (bn_ext) {
             float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H;
-            hipLaunchKernelGGL(k_minmax16, dim3(512), dim3(256), 0, st, (const int16_t *)h, N, H, ext);
+            // layer 0: extremes of the encoder output; later layers: the previous layer's residual pass left them
+            if (li == 0)
+                hipLaunchKernelGGL(k_resid_minmax16<false>, dim3(512), dim3(256), 0, st, (const int16_t *)h,
+                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, 0, 0,
+                                   (const LayerDyn *)nullptr, ext);
             // mode A: the extremes (positive floats) are what the ranks exchange -- one MAX over 2H values
             if (allreduce && allreduce(allreduce_ctx, ext, 2 * H, (void *)st)) return S5FXP_EHIP;
             hipLaunchKernelGGL(k_bn_finalize_mm, dim3(1), dim3(256), 0, st, bn, (const float *)ext, H, d, status, st_exps);
@@ -298,7 +302,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = 32767; // the C projection's 16-bit planes
-        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
+        if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
         if (l.quad_ok) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
@@ -309,7 +313,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             sl.run_if = nullptr;
             hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
         }
-        if (scan_events && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
+        if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
         // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
         GateMArgs ga{};
         bool fused = false;
@@ -392,8 +396,15 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         }
         hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps,
                            (fused && !allreduce) ? 11 : 8);
-        hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z), (const int16_t *)h,
-                           hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
+        if (bn_ext) {
+            float *ext_next = li + 1 < m->n_layers ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H : nullptr;
+            hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(512), dim3(256), 0, st, (const int16_t *)I16(w.z),
+                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, l.res_bits, hb, (const LayerDyn *)d,
+                               ext_next);
+        } else {
+            hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z),
+                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
+        }
         int16_t *sw = h; h = hn; hn = sw;
         hb = l.res_bits;
         he = DynExp{0, &d->res.eo};

@@ -151,7 +151,7 @@ class Engine:
             opts.allreduce = _lib.ALLREDUCE_FN(_cb)
         if scan_events is not None:
             assert len(scan_events) == 2 * self.n_layers
-            arr = (C.c_void_p * len(scan_events))(*[e.cuda_event for e in scan_events])
+            arr = (C.c_void_p * len(scan_events))(*[(e.cuda_event if e is not None else None) for e in scan_events])
             opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
             self._ev_keep = arr
         self._cb_keep = opts
