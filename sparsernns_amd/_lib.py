@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs5fxp.so")
+# S5FXP_LIB: developer override to load an experimental build of the same library (tools/build_variant.sh)
+LIB_PATH = os.environ.get("S5FXP_LIB") or os.path.join(_HERE, "libs5fxp.so")
 
 I32P = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p

@@ -12,7 +12,7 @@
 //
 // LDS: [W_re][W_im][W_out2 (k-permuted)][cs_re][cs_im][D][cs_out2][bias_eff][lut 8][4 wave tiles]
 #pragma once
-#include "mfma_bn.hpp"
+#include "proj_p.hpp"
 
 namespace s5 {
 

@@ -1,0 +1,170 @@
+// proj_p.hpp -- phase-split projection kernels: element work spread over the whole workgroup, one 32-column
+// tile of the matmul per wave.
+//
+// The per-wave kernels in mfma_proj.hpp / mfma_bn.hpp keep a whole frame tile (all k-steps of byte planes,
+// all column tiles of accumulators) in one wave: 200-256 registers, two waves per SIMD, and every stall of
+// the serial load -> chain -> MFMA -> epilogue sequence is exposed.  Here a workgroup of four waves owns a
+// tile of 64 frames:
+//   phase A  all 256 threads: 16-byte coalesced loads of the (64,H) int16 tile, the BatchNorm chain on eight
+//            channels per vector, u stored with 16-byte coalesced stores, byte planes into LDS [frame][k];
+//   phase B  wave w: column tile w of the matmul for both 32-frame halves.  The MFMA runs as D = X * W
+//            (A operand = byte planes from LDS, B operand = this wave's weight columns, held in registers for
+//            the whole kernel), so a lane owns ONE output channel and 4-frame groups of it -- exactly one
+//            16-byte item of the scan-native stream per (group) and per-channel constants are per-lane
+//            registers.
+// Planes are double buffered: one barrier per tile, phase A of tile i+1 overlaps phase B of tile i in other
+// waves.  ~30 KB LDS and < 128 registers: four workgroups (16 waves) per CU.
+#pragma once
+#include "mfma_bn.hpp"
+
+namespace s5 {
+
+// eight values in int32 registers -> byte planes (2 packed registers each), k order preserved
+__device__ __forceinline__ void planes8_from_i32(const int32_t (&v)[8], v2i &hi, v2i &lo)
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned p01 = perm((unsigned)v[4 * j + 1], (unsigned)v[4 * j], 0x05010400u);
+        const unsigned p23 = perm((unsigned)v[4 * j + 3], (unsigned)v[4 * j + 2], 0x05010400u);
+        lo[j] = (int)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+        hi[j] = (int)perm(p23, p01, 0x07060302u);
+    }
+}
+
+// (sequence, step) of frame n0 + o for a small offset o; b0/t0 belong to n0.  Division only when the tile
+// crosses a sequence boundary.
+__device__ __forceinline__ void frame_bt(int64_t b0, int t0, int o, int L, bool nowrap, int64_t &b, int &t)
+{
+    t = t0 + o;
+    b = b0;
+    if (!nowrap) {
+        b += t / L;
+        t = t % L;
+    }
+}
+
+template <int KS, int NT, bool TRACE>
+__global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
+{
+    constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
+    constexpr int VPF = H / 8;             // 16-byte vectors per frame
+    constexpr int NV = FT * VPF / 256;     // vectors per thread and tile
+    constexpr int NCT = NT / 4;            // column tiles per wave
+    constexpr int PLANE = FT * KP;
+    static_assert(FT * VPF % 256 == 0 && NT % 4 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int32_t *tab = reinterpret_cast<int32_t *>(smem);             // 4*H BatchNorm operands
+    int8_t *Xh = smem + 16 * H, *Xl = Xh + 2 * PLANE;             // [buf][frame][KP]
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int64_t tiles = (a.N + FT - 1) / FT;
+    int64_t tile = blockIdx.x;
+
+    v4i raw[NV];
+    auto fetch = [&](int64_t tl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = threadIdx.x + 256 * i;
+            int64_t n = tl * FT + v / VPF;
+            n = n < a.N ? n : a.N - 1;
+            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * H + 8 * (v % VPF));
+        }
+    };
+    if (tile < tiles) fetch(tile);
+    // this wave's weight columns (B operand) and per-channel constants stay in registers
+    v4i wreg[NCT][KS];
+    int32_t csv[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int col = 32 * (wave + 4 * c) + r;
+        csv[c] = a.w.cs128[col];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wreg[c][ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)col * a.w.Kp + 32 * ks + 16 * h);
+    }
+    const LayerDyn d = *a.bn.dyn;
+    const Bn16 bn = bn16_setup(a.bn, d, tab, H);
+    __syncthreads();
+
+    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
+        const int64_t n0 = tile * FT;
+        int8_t *xh = Xh + (it & 1) * PLANE, *xl = Xl + (it & 1) * PLANE;
+        // ---- phase A: BatchNorm chain, u, byte planes
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = threadIdx.x + 256 * i, f = v / VPF, og = v % VPF;
+            const int64_t n = n0 + f;
+            int32_t xin[8], t[8], u[8];
+            unpack8_i16(raw[i], xin);
+            bn16_x4(bn, reinterpret_cast<const int32_t(&)[4]>(xin[0]), 8 * og, reinterpret_cast<int32_t(&)[4]>(t[0]),
+                    reinterpret_cast<int32_t(&)[4]>(u[0]));
+            bn16_x4(bn, reinterpret_cast<const int32_t(&)[4]>(xin[4]), 8 * og + 4, reinterpret_cast<int32_t(&)[4]>(t[4]),
+                    reinterpret_cast<int32_t(&)[4]>(u[4]));
+            if (n < a.N) {
+                const v2i p0 = pack4_i16(u[0], u[1], u[2], u[3]), p1 = pack4_i16(u[4], u[5], u[6], u[7]);
+                *reinterpret_cast<v4i *>(a.u + n * H + 8 * og) = v4i{p0[0], p0[1], p1[0], p1[1]};
+                if (TRACE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (a.tr_pre_s5) a.tr_pre_s5[n * H + 8 * og + e] = t[e];
+                        if (a.tr_u) a.tr_u[n * H + 8 * og + e] = u[e];
+                    }
+                }
+            }
+            v2i hi, lo;
+            planes8_from_i32(u, hi, lo);
+            *reinterpret_cast<v2i *>(xh + f * KP + 8 * og) = hi;
+            *reinterpret_cast<v2i *>(xl + f * KP + 8 * og) = lo;
+        }
+        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x); // in flight during phase B
+        __syncthreads();
+        // ---- phase B: this wave's column tile(s), both 32-frame halves
+        const int64_t b0 = n0 / a.L;
+        const int t0 = (int)(n0 - b0 * a.L);
+        const bool nowrap = t0 + FT <= a.L;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int col = 32 * (wave + 4 * c) + r;
+            const int cc = col >= PC ? 1 : 0, p = col - cc * PC;
+            const int rs = cc ? a.rs_im : a.rs_re, bits = cc ? a.bim_bits : a.bre_bits, sh = cc ? a.sh_im : a.sh_re;
+            const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int8_t *rowh = xh + (32 * sub + r) * KP + 16 * h, *rowl = xl + (32 * sub + r) * KP + 16 * h;
+                v16i acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowh + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = wadd(wshl(acc[i], 8), csv[c]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowl + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
+                // rows (frames) (i&3) + 8*(i>>2) + 4*h of this half: registers 4g..4g+3 are one 4-step block
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o = 32 * sub + 8 * g + 4 * h;
+                    if (n0 + o < a.N) {
+                        int64_t b;
+                        int t;
+                        frame_bt(b0, t0, o, a.L, nowrap, b, t);
+                        v4i q;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int32_t bu = sat(asr(acc[4 * g + e], rs), bits);
+                            q[e] = asr(wshl(bu, lsh), rsh);
+                            if (TRACE) {
+                                if (!cc && a.tr_bu_re) a.tr_bu_re[(n0 + o + e) * PC + p] = bu;
+                                if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
+                            }
+                        }
+                        *reinterpret_cast<v4i *>(a.bq + native_word(b, t, p, cc, a.TB, PC)) = q;
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace s5

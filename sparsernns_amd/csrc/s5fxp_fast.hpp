@@ -287,13 +287,16 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
-            const size_t smem = (size_t)a.w.Np * a.w.Kp + (size_t)a.w.Np * 4 + 4 * (size_t)H * 4; // weights + cs128 + BN params
+            // phase-split kernel (proj_p.hpp): 64-frame tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
+            const int64_t tiles64 = (N + 63) / 64, cap = big ? 512 : 1024, per = (tiles64 + cap - 1) / cap;
+            const unsigned pgrid = (unsigned)((tiles64 + per - 1) / per);
+            const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
             if (tr) {
-                if (big) launch_smem(k_bproj_mfma2<6, 8, true>, grid, smem, st, a);
-                else launch_smem(k_bproj_mfma2<3, 4, true>, grid, smem, st, a);
+                if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a);
+                else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a);
             } else {
-                if (big) launch_smem(k_bproj_mfma2<6, 8, false>, grid, smem, st, a);
-                else launch_smem(k_bproj_mfma2<3, 4, false>, grid, smem, st, a);
+                if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a);
+                else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a);
             }
         }
         // ---- recurrence
