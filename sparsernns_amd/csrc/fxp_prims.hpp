@@ -15,28 +15,37 @@ __host__ __device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return 
 __host__ __device__ __forceinline__ int32_t wshl(int32_t a, int s) { return (int32_t)((uint32_t)a << s); }
 __host__ __device__ __forceinline__ int32_t asr(int32_t a, int s) { return a >> s; }
 
-// fxp_clip, fxparray.py:329-334,346-357 (signed).  One v_med3_i32.
+// fxp_clip, fxparray.py:329-334,346-357 (signed).  On the device ONE v_med3_i32: the compiler only forms
+// med3 from min/max with constant bounds, so it is spelled out (bounds are uniform and hoisted).
 __host__ __device__ __forceinline__ int32_t sat(int32_t v, int bits)
 {
     const int32_t hi = (int32_t)((1u << (bits - 1)) - 1u);
     const int32_t lo = ~hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#else
     return v > hi ? hi : (v < lo ? lo : v);
+#endif
 }
 
 // fxp_change_exp, fxparray.py:310-326: unchanged exponent -> NO clip; otherwise shift and clip
-// at the operand's CURRENT bits.
+// at the operand's CURRENT bits.  Branch-free: one of the two shifts is by zero, and "no clip" is a clip at
+// 32 bits (the identity).
 __host__ __device__ __forceinline__ int32_t chexp(int32_t d, int bits, int e, int e2)
 {
-    if (e2 == e) return d;
-    return sat(e2 > e ? wshl(d, e2 - e) : asr(d, e - e2), bits);
+    const int l = e2 > e ? e2 - e : 0, r = e > e2 ? e - e2 : 0;
+    return sat(asr(wshl(d, l), r), e2 == e ? 32 : bits);
 }
 
-// fxp_change_cfg, fxparray.py:232-271 (signed, FLOOR).
+// fxp_change_cfg, fxparray.py:232-271 (signed, FLOOR): change_exp, then a clip at the new bits if they are
+// fewer.  Two nested symmetric clips are one clip at the smaller width.
 __host__ __device__ __forceinline__ int32_t chcfg(int32_t d, int bits, int e, int bits2, int e2)
 {
-    if (bits == bits2 && e == e2) return d;
-    d = chexp(d, bits, e, e2);
-    return bits > bits2 ? sat(d, bits2) : d;
+    const int l = e2 > e ? e2 - e : 0, r = e > e2 ? e - e2 : 0;
+    const int b1 = e2 == e ? 32 : bits, b2 = bits > bits2 ? bits2 : 32;
+    return sat(asr(wshl(d, l), r), b1 < b2 ? b1 : b2);
 }
 
 // FxpArray.to_float, fxparray.py:72-73: int32 -> f32 (RNE) then an exact power-of-two scale.

@@ -225,4 +225,260 @@ __global__ __launch_bounds__(256, 2) void k_cgate_mfma(CGateArgs a)
     block_max_atomic<3>(mx, a.dynw->mx + 8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Phase-split version (see proj_p.hpp for the idea).  Workgroup = six waves, tile = 64 frames:
+//   A   all threads: one 32-byte stream item (state p, 4 steps, re+im) per thread -> range check, complex
+//       ReLU, 4x4 transpose inside the lane quad (DPP) so that a lane holds 4 consecutive states of ONE
+//       frame -> byte planes S[frame][re P | im P] in LDS;
+//   B1  wave (half, ct): C projection of its 32 channels x 32 frames, weights in registers, epilogue ->
+//       x1 (kept in registers for the gate) and its byte planes X1[frame][H] in LDS;
+//   B2  the same wave: out2 for the same channels/frames from the X1 planes (natural k order), LUT sigmoid,
+//       gate, int16 store, residual maxima.
+// No weights in LDS (35 KB at dim 0.5, 65 KB at dim 1.0), ~128 registers.
+// LDS: [cs_re][cs_im][D][cs_out2][bias_eff] (Np ints each) [lut pairs 8] [S hi][S lo][X1 hi][X1 lo] [red 3x8]
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int32_t quad_xchg(int32_t v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+// 4x4 transpose of w[0..3] across the four lanes of a quad: lane q's w[j] <-> lane j's w[q]
+__device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    { // bit 0: register pairs (0,1), (2,3); partner = lane ^ 1
+        const int32_t r01 = quad_xchg<0xB1>(b0 ? w[0] : w[1]), r23 = quad_xchg<0xB1>(b0 ? w[2] : w[3]);
+        w[0] = b0 ? r01 : w[0]; w[1] = b0 ? w[1] : r01;
+        w[2] = b0 ? r23 : w[2]; w[3] = b0 ? w[3] : r23;
+    }
+    { // bit 1: register pairs (0,2), (1,3); partner = lane ^ 2
+        const int32_t r02 = quad_xchg<0x4E>(b1 ? w[0] : w[2]), r13 = quad_xchg<0x4E>(b1 ? w[1] : w[3]);
+        w[0] = b1 ? r02 : w[0]; w[2] = b1 ? w[2] : r02;
+        w[1] = b1 ? r13 : w[1]; w[3] = b1 ? w[3] : r13;
+    }
+}
+
+template <int KSTEPS>
+__device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], const int8_t *rowh, const int8_t *rowl,
+                                            const int32_t *cs)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowh + 32 * ks), acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const v4i c = *reinterpret_cast<const v4i *>(cs + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = wadd(wshl(acc[4 * g + e], 8), c[e]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowl + 32 * ks), acc, 0, 0, 0);
+}
+
+template <int KS, int NT, bool TRACE>
+__global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
+{
+    constexpr int P = 32 * KS, H = 32 * NT, FT = 64, NW = 6;
+    constexpr int KPS = 2 * P + 16, KPX = H + 16;
+    constexpr int NU = 2 * NT / NW;      // (half, column tile) units per wave: 1 (H=96) or 2 (H=192)
+    constexpr int SUBSTEP = NW / NT;     // 2 or 1
+    constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + 383) / 384;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
+    int8_t *Sh = reinterpret_cast<int8_t *>(lutp + 8), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
+    float *red = reinterpret_cast<float *>(Xl + FT * KPX);
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int ct = wave % NT, sub0 = wave / NT;
+    const int64_t tiles = (a.N + FT - 1) / FT;
+
+    // weights of this wave's 32 channels (A operand rows), all k-steps, in registers
+    v4i wre[KS], wim[KS], wo2[NT];
+    {
+        const size_t row = (size_t)(32 * ct + r);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            wre[ks] = *reinterpret_cast<const v4i *>(a.w_re.wt + row * a.w_re.Kp + 32 * ks + 16 * h);
+            wim[ks] = *reinterpret_cast<const v4i *>(a.w_im.wt + row * a.w_im.Kp + 32 * ks + 16 * h);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NT; ++ks) wo2[ks] = *reinterpret_cast<const v4i *>(a.w_o2.wt + row * a.w_o2.Kp + 32 * ks + 16 * h);
+    }
+    for (int i = threadIdx.x; i < H; i += 384) {
+        csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i]; be[i] = a.bias_eff[i];
+    }
+    if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
+    const int skip_e = a.skip_e.get();
+    const float kz = ldexpf(1.f, skip_e - a.res_exp); // fz + fs = 2^-skip_e * (z * kz + s), exactly
+    const int sx = a.sig_x, S = 1 << sx;
+    // out2 input conversion (fxpmodel.py:335-347) as uniform shift/clip operands; identity when not needed
+    const int cv_l = a.conv && a.inp_exp > a.y_exp ? a.inp_exp - a.y_exp : 0, cv_r = a.conv && a.y_exp > a.inp_exp ? a.y_exp - a.inp_exp : 0;
+    const int cv_b1 = a.conv && a.inp_exp != a.y_exp ? a.y_bits : 32, cv_b2 = a.conv && a.y_bits > a.inp_bits ? a.inp_bits : 32;
+    const int cv_b = cv_b1 < cv_b2 ? cv_b1 : cv_b2;
+    uint32_t xrange = 0;
+    float mx[3] = {0.f, 0.f, 0.f}; // |z*kz + s|, |z|, |s| as converted integers; scaled once at the end
+    const int ch0 = 32 * ct + 4 * h;
+    __syncthreads();
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * FT;
+        const int64_t b0 = n0 / a.L;
+        const int t0 = (int)(n0 - b0 * a.L);
+        const bool nowrap = t0 + FT <= a.L;
+        // ---- u and skip of this wave's units: requested first, consumed in the epilogues
+        v2i uq[NU][4], sq[NU][4];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int64_t n = n0 + 32 * (sub0 + u * SUBSTEP) + r;
+            n = n < a.N ? n : a.N - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uq[u][g] = *reinterpret_cast<const v2i *>(a.u + n * H + ch0 + 8 * g);
+                sq[u][g] = *reinterpret_cast<const v2i *>(a.skip + n * H + ch0 + 8 * g);
+            }
+        }
+        // ---- phase A: stream items -> byte planes
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int q = threadIdx.x + 384 * i;
+            if (ROUNDS * 384 == ITEMS || q < ITEMS) {
+                const int grp = q / P, p = q % P;
+                int o = 4 * grp;
+                if (n0 + o >= a.N) o = (int)(a.N - 4 - n0); // partial tile: re-read the last block (results unused)
+                int64_t b;
+                int t;
+                frame_bt(b0, t0, o, a.L, nowrap, b, t);
+                const int32_t *src = a.xs + native_word(b, t, p, 0, a.TB, P);
+                const v4i cre = *reinterpret_cast<const v4i *>(src), cim = *reinterpret_cast<const v4i *>(src + 4);
+                int32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int32_t xr = cre[j], xi = cim[j];
+                    const uint32_t ur = (uint32_t)(xr + a.xmax), ui = (uint32_t)(xi + a.xmax);
+                    xrange = xrange > ur ? xrange : ur;
+                    xrange = xrange > ui ? xrange : ui;
+                    // complex ReLU = lexicographic max(z, 0); exact in integers while |x| <= xmax < 2^24
+                    const bool keep = (xr > 0) | ((xr == 0) & (xi > 0));
+                    w[j] = keep ? (int32_t)perm((unsigned)xi, (unsigned)xr, 0x05040100u) : 0;
+                }
+                quad_transpose(w, l);
+                // now: this lane = frame 4*grp + (l&3), w[m] = (re | im << 16) of state (p & ~3) + m
+                const unsigned t01 = perm((unsigned)w[1], (unsigned)w[0], 0x05010400u), u01 = perm((unsigned)w[1], (unsigned)w[0], 0x07030602u);
+                const unsigned t23 = perm((unsigned)w[3], (unsigned)w[2], 0x05010400u), u23 = perm((unsigned)w[3], (unsigned)w[2], 0x07030602u);
+                const int row = (4 * grp + (l & 3)) * KPS + (p & ~3);
+                *reinterpret_cast<int32_t *>(Sl + row) = (int32_t)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+                *reinterpret_cast<int32_t *>(Sh + row) = (int32_t)perm(t23, t01, 0x07060302u);
+                *reinterpret_cast<int32_t *>(Sl + row + P) = (int32_t)(perm(u23, u01, 0x05040100u) ^ 0x80808080u);
+                *reinterpret_cast<int32_t *>(Sh + row + P) = (int32_t)perm(u23, u01, 0x07060302u);
+            }
+        }
+        __syncthreads();
+        // ---- phase B1: C projection + first epilogue
+        int32_t x1v[NU][16];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int sub = sub0 + u * SUBSTEP;
+            const int64_t n = n0 + 32 * sub + r;
+            const int8_t *rowh = Sh + (32 * sub + r) * KPS + 16 * h, *rowl = Sl + (32 * sub + r) * KPS + 16 * h;
+            v16i are, aim;
+            mfma_planes<KS>(are, wre, rowh, rowl, csr + ch0);
+            mfma_planes<KS>(aim, wim, rowh + P, rowl + P, csi + ch0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i Dv = *reinterpret_cast<const v4i *>(Dl + ch0 + 8 * g);
+                int32_t uv[4], xv[4];
+                unpack4_i16(uq[u][g], uv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int32_t cr = sat(asr(are[4 * g + e], a.rs_re), a.y_bits);
+                    const int32_t ci = sat(asr(aim[4 * g + e], a.rs_im), a.y_bits);
+                    const int32_t cx = sat(cr - ci, a.y_bits);
+                    const int32_t du = sat(asr(__mul24(Dv[e], uv[e]), a.rs_d), a.y_bits);
+                    const int32_t y = sat(2 * cx + du, a.y_bits); // 2*cx is not clipped, fxpmodel.py:765-767
+                    if (TRACE) {
+                        if (a.tr_ys && n < a.N) a.tr_ys[n * H + ch0 + 8 * g + e] = y;
+                    }
+                    const int32_t x1 = y < 0 ? 0 : y;
+                    x1v[u][4 * g + e] = x1;
+                    xv[e] = sat(asr(wshl(x1, cv_l), cv_r), cv_b);
+                }
+                const unsigned p01 = perm((unsigned)xv[1], (unsigned)xv[0], 0x05010400u), p23 = perm((unsigned)xv[3], (unsigned)xv[2], 0x05010400u);
+                const int off = (32 * sub + r) * KPX + ch0 + 8 * g;
+                *reinterpret_cast<int32_t *>(Xl + off) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                *reinterpret_cast<int32_t *>(Xh + off) = (int32_t)perm(p23, p01, 0x07060302u);
+            }
+        }
+        __syncthreads();
+        // ---- phase B2: out2 + second epilogue
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int sub = sub0 + u * SUBSTEP;
+            const int64_t n = n0 + 32 * sub + r;
+            v16i acc;
+            mfma_planes<NT>(acc, wo2, Xh + (32 * sub + r) * KPX + 16 * h, Xl + (32 * sub + r) * KPX + 16 * h, cs2 + ch0);
+            if (n < a.N) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = ch0 + 8 * g;
+                    const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
+                    int32_t sv[4], o[4];
+                    unpack4_i16(sq[u][g], sv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int32_t gq = sat(asr(acc[4 * g + e], a.rs_o2), a.out_bits);
+                        gq = sat(gq + bv[e], a.out_bits);
+                        // LUT sigmoid (fxp_prims.hpp sigmoid_lut) with the two table entries in one LDS word
+                        const int32_t xx = chexp(gq, a.out_bits, a.out_exp, sx);
+                        const int32_t ax = xx < 0 ? -xx : xx;
+                        int32_t ind = ax >> sx;
+                        ind = ind > 6 ? 6 : ind;
+                        const int32_t mu = ax & (S - 1);
+                        const uint32_t pr = (uint32_t)lutp[ind];
+                        const int32_t half = (__mul24(S - mu, (int32_t)(pr & 0xffffu)) >> sx) + (__mul24(mu, (int32_t)(pr >> 16)) >> sx);
+                        const int32_t s = (1 << (a.sig_y - 1)) + (xx > 0 ? half : -half);
+                        const int32_t lq = chcfg(x1v[u][4 * g + e], a.y_bits, a.y_exp, a.l_bits, a.l_exp);
+                        const int32_t rq = chcfg(s, a.out_bits, a.sig_y, a.r_bits, a.r_exp);
+                        const int32_t z = sat(asr(__mul24(lq, rq), a.rs_gate), a.res_bits);
+                        if (TRACE) {
+                            if (a.tr_out2) a.tr_out2[n * H + ch + e] = gq;
+                            if (a.tr_sig) a.tr_sig[n * H + ch + e] = s;
+                            if (a.tr_z) a.tr_z[n * H + ch + e] = z;
+                        }
+                        o[e] = z;
+                        const float cz = (float)z, cs = (float)sv[e];
+                        mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cz, kz, cs)));
+                        mx[1] = fmaxf(mx[1], fabsf(cz));
+                        mx[2] = fmaxf(mx[2], fabsf(cs));
+                    }
+                    *reinterpret_cast<v2i *>(a.z + n * H + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
+    if (__any(xrange > 2u * (uint32_t)a.xmax) && l == 0) {
+        atomicExch(&a.dynw->redo, 1);
+        atomicOr(a.status, ST_WIDE_STATE);
+    }
+    mx[0] = ldexpf(mx[0], -skip_e);
+    mx[1] = ldexpf(mx[1], -a.res_exp);
+    mx[2] = ldexpf(mx[2], -skip_e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float x = mx[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+        if (l == 0) red[i * 8 + wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float x = red[threadIdx.x * 8];
+        for (int w = 1; w < NW; ++w) x = fmaxf(x, red[threadIdx.x * 8 + w]);
+        atomicMax(a.dynw->mx + 8 + threadIdx.x, __float_as_uint(x));
+    }
+}
+
 } // namespace s5

@@ -60,8 +60,10 @@ bool fast_eligible(const s5fxp_model_desc *d)
         if (!dense16(l.out2) || l.l_bits > 16 || l.r_bits > 16 || l.res_bits > 16) return false;
         if (!fits_bits(s.B_re, (size_t)P * H, 8) || !fits_bits(s.B_im, (size_t)P * H, 8) ||
             !fits_bits(s.C_re, (size_t)H * P, 8) || !fits_bits(s.C_im, (size_t)H * P, 8) ||
-            !fits_bits(l.out2.weight, (size_t)H * H, 8))
+            !fits_bits(l.out2.weight, (size_t)H * H, 8) || !fits_bits(s.D, (size_t)H, 16))
             return false;
+        for (int i8 = 0; i8 < 8; ++i8) // the fused gate kernel keeps two LUT entries per 32-bit word
+            if (l.lut[i8] < 0 || l.lut[i8] > 65535) return false;
     }
     return true;
 }
@@ -337,7 +339,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         }
         {
             CGateArgs a{};
-            a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2p.w;
+            a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2.w;
             a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z);
             a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H;
@@ -348,26 +350,22 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             std::memcpy(a.lut, l.lut, sizeof(a.lut));
             a.l_bits = l.l_bits; a.l_exp = l.l_exp; a.r_bits = l.r_bits; a.r_exp = l.r_exp; a.res_bits = l.res_bits;
             a.res_exp = l.res_exp; a.rs_gate = ga.rs_gate; a.skip_e = he; a.dynw = d; a.status = status;
-            const size_t np = (size_t)a.w_re.Np;
-            const size_t smem = 2 * np * a.w_re.Kp + (size_t)a.w_o2.Np * a.w_o2.Kp + 5 * np * 4 + 32 + 4 * 32 * (size_t)(4 * P + 16);
-            fused = smem <= 160 * 1024; // the dim_scale 1.0 tile set does not fit one CU's LDS: two kernels there
-            if (fused) {
-                if (tr) {
-                    if (big) launch_smem(k_cgate_mfma<4, 6, true>, grid, smem, st, a);
-                    else launch_smem(k_cgate_mfma<2, 3, true>, grid, smem, st, a);
-                } else {
-                    if (big) launch_smem(k_cgate_mfma<4, 6, false>, grid, smem, st, a);
-                    else launch_smem(k_cgate_mfma<2, 3, false>, grid, smem, st, a);
-                }
+            // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
+            fused = true;
+            const int64_t tiles64 = (N + 63) / 64, cap = 512, per = (tiles64 + cap - 1) / cap;
+            const unsigned cgrid = (unsigned)((tiles64 + per - 1) / per);
+            const size_t smem = 5 * (size_t)H * 4 + 32 + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
+            auto launch6 = [&](auto kernel) {
+                if (smem > 65536)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                hipLaunchKernelGGL(kernel, dim3(cgrid), dim3(384), smem, st, a);
+            };
+            if (tr) {
+                if (big) launch6(k_cgate_p<4, 6, true>);
+                else launch6(k_cgate_p<2, 3, true>);
             } else {
-                CprojMArgs c{};
-                c.bn = bn; c.x = I16(w.u); c.have_u = 1; c.xs = I32(w.xs); c.w_re = fl.cre.w; c.w_im = fl.cim.w; c.D = fl.Dpad;
-                c.x1 = I16(w.x1); c.tr_ys = tr ? tr->ys : nullptr; c.N = N; c.L = L; c.TB = w.TB; c.H = H; c.P = P;
-                c.rs_re = a.rs_re; c.rs_im = a.rs_im; c.rs_d = a.rs_d; c.y_bits = s.y_bits; c.xmax = xmax; c.dynw = d;
-                c.status = status;
-                const size_t smc = 2 * np * c.w_re.Kp + 3 * np * 4 + 4 * 32 * (size_t)(4 * P + 16);
-                if (big) launch_smem(k_cproj_mfma<4, 6>, grid, smc, st, c);
-                else launch_smem(k_cproj_mfma<2, 3>, grid, smc, st, c);
+                if (big) launch6(k_cgate_p<4, 6, false>);
+                else launch6(k_cgate_p<2, 3, false>);
             }
             // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo)
             if (l.quad_ok) {
