@@ -259,26 +259,6 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
     }
 }
 
-template <int KSTEPS>
-__device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], const int8_t *rowh, const int8_t *rowl,
-                                            const int32_t *cs)
-{
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowh + 32 * ks), acc, 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const v4i c = *reinterpret_cast<const v4i *>(cs + 8 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = wadd(wshl(acc[4 * g + e], 8), c[e]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowl + 32 * ks), acc, 0, 0, 0);
-}
-
 template <int KS, int NT, bool TRACE>
 __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
 {

@@ -167,4 +167,237 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
     }
 }
 
+// uniform operands of a change_cfg (fxp_prims.hpp chcfg) applied to many elements; `on` false = identity
+struct CfgOp {
+    int l, r, b;
+    __device__ __forceinline__ int32_t operator()(int32_t d) const { return sat(asr(wshl(d, l), r), b); }
+};
+__device__ __forceinline__ CfgOp make_cfg(bool on, int bits, int e, int bits2, int e2)
+{
+    CfgOp c;
+    c.l = on && e2 > e ? e2 - e : 0;
+    c.r = on && e > e2 ? e - e2 : 0;
+    const int b1 = on && e2 != e ? bits : 32, b2 = on && bits > bits2 ? bits2 : 32;
+    c.b = b1 < b2 ? b1 : b2;
+    return c;
+}
+
+// two-plane MFMA, A operand (weights, rows = channels) in registers, B operand (byte planes) from LDS:
+// lane = frame, registers = channels (i&3) + 8*(i>>2) + 4*(lane>>5) of the 32-channel tile
+template <int KSTEPS>
+__device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], const int8_t *rowh, const int8_t *rowl,
+                                            const int32_t *cs)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowh + 32 * ks), acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const v4i c = *reinterpret_cast<const v4i *>(cs + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = wadd(wshl(acc[4 * g + e], 8), c[e]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowl + 32 * ks), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder, phase-split: x int32 (N,K) -> relu(dense) int16 (N,H).  fxpmodel.py:331-366, 1263-1266.
+// Six waves, 64-frame tiles.  Phase A: a wave reads whole rows (64 lanes x 4 consecutive k, 1 KB contiguous)
+// plus the K-256 tail, converts, and writes byte planes [frame][304]; phase B: wave (half, column tile).
+// LDS: [cs128 Np][bias_eff Np][X hi][X lo]
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(384, 2) void k_enc_p(EncArgs a)
+{
+    constexpr int KS = 9, FT = 64, KP = 32 * KS + 16, NW = 6, H = 32 * NT;
+    constexpr int NU = 2 * NT / NW, SUBSTEP = NW / NT;
+    constexpr int RPW = (FT + NW - 1) / NW; // rows per wave
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int32_t *cs = reinterpret_cast<int32_t *>(smem), *be = cs + H;
+    int8_t *Xh = reinterpret_cast<int8_t *>(be + H), *Xl = Xh + FT * KP;
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int ct = wave % NT, sub0 = wave / NT, ch0 = 32 * ct + 4 * h;
+    const int64_t tiles = (a.N + FT - 1) / FT;
+    const int K = a.K, rem = K - 256;
+    v4i wreg[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        wreg[ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)(32 * ct + r) * a.w.Kp + 32 * ks + 16 * h);
+    for (int i = threadIdx.x; i < H; i += 384) {
+        cs[i] = a.w.cs128[i];
+        be[i] = a.bias_eff[i];
+    }
+    const CfgOp cv = make_cfg(a.conv != 0, a.xb, a.xe, a.inp_bits, a.inp_exp);
+    v4i raw[RPW];
+    auto fetch = [&](int64_t tl) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            int64_t n = tl * FT + wave + NW * i;
+            n = n < a.N ? n : a.N - 1;
+            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * K + 4 * l); // 4-byte aligned 16-byte load
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    bool wide = false;
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * FT;
+        // ---- phase A
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int f = wave + NW * i;
+            if (f < FT) {
+                int32_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = cv(raw[i][e]);
+                    wide |= (v[e] != (int32_t)(int16_t)v[e]);
+                }
+                const unsigned p01 = perm((unsigned)v[1], (unsigned)v[0], 0x05010400u), p23 = perm((unsigned)v[3], (unsigned)v[2], 0x05010400u);
+                *reinterpret_cast<int32_t *>(Xl + f * KP + 4 * l) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+                *reinterpret_cast<int32_t *>(Xh + f * KP + 4 * l) = (int32_t)perm(p23, p01, 0x07060302u);
+            }
+        }
+        for (int e = threadIdx.x; e < FT * rem; e += 384) { // the K-256 tail of every row
+            const int f = e / rem, k = 256 + e % rem;
+            int64_t n = n0 + f;
+            n = n < a.N ? n : a.N - 1;
+            const int32_t v = cv(a.x[n * K + k]);
+            wide |= (v != (int32_t)(int16_t)v);
+            Xl[f * KP + k] = (int8_t)((v & 0xff) ^ 0x80);
+            Xh[f * KP + k] = (int8_t)(v >> 8);
+        }
+        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x); // in flight during phase B
+        __syncthreads();
+        // ---- phase B
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int sub = sub0 + u * SUBSTEP;
+            const int64_t n = n0 + 32 * sub + r;
+            v16i acc;
+            mfma_planes<KS>(acc, wreg, Xh + (32 * sub + r) * KP + 16 * h, Xl + (32 * sub + r) * KP + 16 * h, cs + ch0);
+            if (n < a.N) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = ch0 + 8 * g;
+                    if (ch < a.M) {
+                        const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
+                        int32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int32_t v = sat(asr(acc[4 * g + e], a.rs), a.out_bits);
+                            v = sat(wadd(v, bv[e]), a.out_bits);
+                            o[e] = v < 0 ? 0 : v;
+                        }
+                        *reinterpret_cast<v2i *>(a.y + n * a.M + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // planes are single-buffered
+    }
+    if (__any(wide) && l == 0) atomicOr(a.status, ST_WIDE_INPUT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder, phase-split: h int16 (N,H) -> dense int32 (N,M), M <= 288.  fxpmodel.py:331-366, 1272-1274.
+// Six waves, 64-frame tiles.  Phase B runs as D = X * W (lane = output column, registers = frames): every
+// store instruction writes 128 contiguous bytes of one output row per half wave.
+// LDS: [X hi][X lo]
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a)
+{
+    constexpr int H = 32 * KS, FT = 64, KP = H + 16, NW = 6, CT = 9, CPW = 3;
+    constexpr int VPF = H / 8, NV = FT * VPF / 384;
+    static_assert(FT * VPF % 384 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int8_t *Xh = smem, *Xl = Xh + FT * KP;
+    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int sub = wave / 3, c0 = wave % 3;
+    const int64_t tiles = (a.N + FT - 1) / FT;
+    const int xe0 = a.xe.get();
+    const bool conv = a.xb > a.inp_bits || xe0 > a.inp_exp;
+    int rs = (conv ? a.inp_exp : xe0) + a.w_exp - a.out_exp;
+    if (rs < 0 || rs > 31) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(a.status, ST_NEGSHIFT);
+        rs = rs < 0 ? 0 : 31;
+    }
+    const CfgOp cv = make_cfg(conv, a.xb, xe0, a.inp_bits, a.inp_exp);
+    v4i wreg[CPW][KS];
+    int32_t csv[CPW], bev[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int col = 32 * (c0 + 3 * c) + r;
+        csv[c] = a.w.cs128[col];
+        bev[c] = a.bias_eff[col];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            wreg[c][ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)col * a.w.Kp + 32 * ks + 16 * h);
+    }
+    v4i raw[NV];
+    auto fetch = [&](int64_t tl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = threadIdx.x + 384 * i;
+            int64_t n = tl * FT + v / VPF;
+            n = n < a.N ? n : a.N - 1;
+            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * H + 8 * (v % VPF));
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) fetch(tile);
+    for (; tile < tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * FT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = threadIdx.x + 384 * i, f = v / VPF, og = v % VPF;
+            int32_t x[8];
+            unpack8_i16(raw[i], x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = cv(x[e]);
+            v2i hi, lo;
+            planes8_from_i32(x, hi, lo);
+            *reinterpret_cast<v2i *>(Xh + f * KP + 8 * og) = hi;
+            *reinterpret_cast<v2i *>(Xl + f * KP + 8 * og) = lo;
+        }
+        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);
+        __syncthreads();
+        const int8_t *rowh = Xh + (32 * sub + r) * KP + 16 * h, *rowl = Xl + (32 * sub + r) * KP + 16 * h;
+        const int64_t nb = n0 + 32 * sub + 4 * h; // frame of accumulator register 0
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int col = 32 * (c0 + 3 * c) + r;
+            v16i acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowh + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = wadd(wshl(acc[i], 8), csv[c]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowl + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
+            if (col < a.M) {
+                int32_t *dst = a.y + nb * a.M + col;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int fo = (i & 3) + 8 * (i >> 2);
+                    if (nb + fo < a.N) {
+                        const int32_t v = sat(asr(acc[i], rs), a.out_bits);
+                        dst[(int64_t)fo * a.M] = sat(wadd(v, bev[c]), a.out_bits);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // planes are single-buffered
+    }
+}
+
 } // namespace s5

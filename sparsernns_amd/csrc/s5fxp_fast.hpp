@@ -210,6 +210,15 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                  m->layers[li].res_bits <= 16;
     }
 
+    // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles, two workgroups per CU
+    const int64_t tiles64 = (N + 63) / 64, per6 = (tiles64 + 511) / 512;
+    const unsigned grid6 = (unsigned)((tiles64 + per6 - 1) / per6);
+    auto launch6 = [&](auto kernel, size_t smem, const auto &args) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kernel, dim3(grid6), dim3(384), smem, st, args);
+    };
+
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
     // ---- encoder + ReLU
     {
@@ -221,9 +230,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         a.rs = (a.conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp;
         if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
         a.out_bits = e.out_bits; a.status = status;
-        const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4; // weights + cs128 + bias_eff
-        if (big) launch_smem(k_enc_mfma<9, 6>, grid, smem, st, a);
-        else launch_smem(k_enc_mfma<9, 3>, grid, smem, st, a);
+        const size_t smem = 2 * (size_t)H * 4 + 2 * 64 * 304; // cs128 + bias_eff + byte planes
+        if (big) launch6(k_enc_p<6>, smem, a);
+        else launch6(k_enc_p<3>, smem, a);
     }
     int hb = m->enc.out_bits;
     DynExp he{m->enc.out_exp, nullptr};
@@ -352,20 +361,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.res_exp = l.res_exp; a.rs_gate = ga.rs_gate; a.skip_e = he; a.dynw = d; a.status = status;
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
-            const int64_t tiles64 = (N + 63) / 64, cap = 512, per = (tiles64 + cap - 1) / cap;
-            const unsigned cgrid = (unsigned)((tiles64 + per - 1) / per);
             const size_t smem = 5 * (size_t)H * 4 + 32 + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
-            auto launch6 = [&](auto kernel) {
-                if (smem > 65536)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipLaunchKernelGGL(kernel, dim3(cgrid), dim3(384), smem, st, a);
-            };
             if (tr) {
-                if (big) launch6(k_cgate_p<4, 6, true>);
-                else launch6(k_cgate_p<2, 3, true>);
+                if (big) launch6(k_cgate_p<4, 6, true>, smem, a);
+                else launch6(k_cgate_p<2, 3, true>, smem, a);
             } else {
-                if (big) launch6(k_cgate_p<4, 6, false>);
-                else launch6(k_cgate_p<2, 3, false>);
+                if (big) launch6(k_cgate_p<4, 6, false>, smem, a);
+                else launch6(k_cgate_p<2, 3, false>, smem, a);
             }
             // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo)
             if (l.quad_ok) {
@@ -417,9 +419,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         a.x = h; a.y = y; a.w = F.dec.w; a.bias_eff = F.dec.bias_eff; a.N = N; a.H = H; a.M = e.M;
         a.xb = hb; a.xe = he; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.w_exp = e.w_exp;
         a.out_bits = e.out_bits; a.out_exp = e.out_exp; a.status = status;
-        const size_t smem = (size_t)a.w.Np * a.w.Kp + 2 * (size_t)a.w.Np * 4;
-        if (big) launch_smem(k_dec_mfma<6, 3, 3>, grid, smem, st, a);
-        else launch_smem(k_dec_mfma<3, 3, 3>, grid, smem, st, a);
+        const size_t smem = 2 * 64 * (size_t)(H + 16);
+        if (big) launch6(k_dec_p<6>, smem, a);
+        else launch6(k_dec_p<3>, smem, a);
     }
     return launch_rc();
 }
