@@ -183,9 +183,20 @@ enum {
     S5FXP_ST_NEGSHIFT = 1,   /* a data-dependent shift came out negative: the reference raises ValueError */
     S5FXP_ST_NEGEXP = 2,     /* a compute_best exponent came out negative (1 << exp fails in the reference) */
     S5FXP_ST_WIDE_STATE = 4, /* informational: an SSM state exceeded 24 bits, the 32-bit C projection ran */
-    S5FXP_ST_WIDE_INPUT = 8  /* the input tensor holds values beyond 24 bits: results invalid, re-run with a
+    S5FXP_ST_WIDE_INPUT = 8, /* the input tensor holds values beyond 24 bits: results invalid, re-run with a
                                 model created with S5FXP_MODEL_FORCE_GENERIC */
+    S5FXP_ST_REDO = 16       /* only with S5FXP_FWD_DEFER_REDO: a state left the fast recurrence's exact range and
+                                the exact re-run was NOT enqueued: results invalid, call again with
+                                S5FXP_FWD_EXACT */
 };
+
+/* s5fxp_forward_opts.flags.  By default a forward is self-contained: next to the fast recurrence it enqueues
+ * the exact 32-bit kernels, gated on a device flag, so the output is right whatever the data.  A caller that
+ * reads the status words anyway can drop those (normally idle) launches:
+ *   DEFER_REDO  do not enqueue the gated exact kernels; S5FXP_ST_REDO in status[0] tells the caller to repeat
+ *               the forward with S5FXP_FWD_EXACT;
+ *   EXACT       skip the fast recurrence, run the exact kernels only. */
+enum { S5FXP_FWD_DEFER_REDO = 1, S5FXP_FWD_EXACT = 2 };
 
 /* Cross-rank hook for the data-dependent exponents (mode A): when not NULL it is
  * called once per compute_best op, after the local float32 maxima (n <= 4 floats, device memory)
@@ -200,6 +211,7 @@ typedef struct {
     /* Measurement only: 2*n_layers hipEvent_t handles (or NULL); events [2l] / [2l+1] are recorded on
      * `stream` immediately before / after layer l's recurrence kernel(s). NULL entries are skipped. */
     void **scan_events;
+    int32_t flags; /* S5FXP_FWD_* */
 } s5fxp_forward_opts;
 
 /* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.

@@ -17,7 +17,8 @@ I32P = C.POINTER(C.c_int32)
 VOIDP = C.c_void_p
 
 S5FXP_OK, S5FXP_EBADARG, S5FXP_ENEGSHIFT, S5FXP_EUNSUPPORTED, S5FXP_EHIP, S5FXP_EWORKSPACE = 0, -1, -2, -3, -4, -5
-ST_NEGSHIFT, ST_NEGEXP, ST_WIDE_STATE, ST_WIDE_INPUT = 1, 2, 4, 8
+ST_NEGSHIFT, ST_NEGEXP, ST_WIDE_STATE, ST_WIDE_INPUT, ST_REDO = 1, 2, 4, 8, 16
+FWD_DEFER_REDO, FWD_EXACT = 1, 2
 STATUS_WORDS = 128
 MODEL_DEFAULT, MODEL_FORCE_DENSE, MODEL_FORCE_CSR, MODEL_FORCE_GENERIC = 0, 1, 2, 4
 
@@ -66,7 +67,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, VOIDP, VOIDP, C.c_int, VOIDP)
 
 
 class ForwardOpts(C.Structure):
-    _fields_ = [("allreduce", ALLREDUCE_FN), ("allreduce_ctx", VOIDP), ("scan_events", C.POINTER(VOIDP))]
+    _fields_ = [("allreduce", ALLREDUCE_FN), ("allreduce_ctx", VOIDP), ("scan_events", C.POINTER(VOIDP)),
+                ("flags", C.c_int32)]
 
 
 class S5FxpError(RuntimeError):

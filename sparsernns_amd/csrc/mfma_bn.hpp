@@ -33,83 +33,6 @@ __device__ __forceinline__ void unpack8_i16(const v4i &w, int32_t (&v)[8])
     }
 }
 
-// Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
-// layer's BatchNorm operand).  RESID=false: extremes of z only (the encoder output ahead of layer 0).
-// block = 256 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes; four frames in flight
-// per thread.  ext == nullptr: no extremes wanted (last layer).
-template <bool RESID>
-__global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
-                                                        int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
-                                                        int res_bits, int skip_bits, const LayerDyn *dyn, float *ext)
-{
-    __shared__ int32_t smin[256 * 8], smax[256 * 8];
-    const int G = H >> 3, R = 256 / G;
-    const int g = threadIdx.x % G, rl = threadIdx.x / G;
-    AddCb p{};
-    if constexpr (RESID) p = dyn->res;
-    int32_t lo[8], hi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        lo[e] = 32767;
-        hi[e] = -32768;
-    }
-    if (rl < R) {
-        const int64_t stride = (int64_t)gridDim.x * R;
-        for (int64_t n0 = (int64_t)blockIdx.x * R + rl; n0 < N; n0 += 4 * stride) {
-            v4i zq[4], sq[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t n = n0 + k * stride;
-                if (n < N) {
-                    zq[k] = *reinterpret_cast<const v4i *>(z + n * H + 8 * g);
-                    if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t n = n0 + k * stride;
-                if (n < N) {
-                    int32_t v[8], s[8];
-                    unpack8_i16(zq[k], v);
-                    if constexpr (RESID) {
-                        unpack8_i16(sq[k], s);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
-                            if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
-                            v[e] = rr < 0 ? 0 : rr;
-                        }
-                        const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
-                        *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        lo[e] = v[e] < lo[e] ? v[e] : lo[e];
-                        hi[e] = v[e] > hi[e] ? v[e] : hi[e];
-                    }
-                }
-            }
-        }
-    }
-    if (!ext) return;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        smin[threadIdx.x * 8 + e] = lo[e];
-        smax[threadIdx.x * 8 + e] = hi[e];
-    }
-    __syncthreads();
-    if (threadIdx.x < H) { // one thread per channel folds the R frame lanes
-        const int c = threadIdx.x;
-        int32_t a = 32767, b = -32768;
-        for (int r = 0; r < R; ++r) {
-            a = min(a, smin[r * G * 8 + c]);
-            b = max(b, smax[r * G * 8 + c]);
-        }
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)a));
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + H + c, __float_as_uint(EXT_BIAS + (float)b));
-    }
-}
-
 // block reduce of NV float maxima over blockDim.x threads (every thread gets the result)
 template <int NV>
 __device__ __forceinline__ void block_allmax(float (&v)[NV], float (*red)[8])
@@ -134,15 +57,22 @@ __device__ __forceinline__ void block_allmax(float (&v)[NV], float (*red)[8])
 
 // One workgroup (256 threads >= H): thread h owns channel h and walks its two end points through the
 // BatchNorm stages; between stages the workgroup reduces the maxima and thread 0 derives the exponent.
-__global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *ext, int H, LayerDyn *d, int32_t *status,
-                                                        int32_t *status_exps)
+// Callable by any 256-thread workgroup: as its own kernel (k_bn_finalize_mm) or as the tail of the kernel that
+// produced the extremes, run by the workgroup that finished last (k_resid_minmax16).  There the extremes were
+// written by other workgroups' atomics, possibly on other XCDs: agent-scope loads, not cached ones.
+__device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float *ext, int H, LayerDyn *d, int32_t *status,
+                                                    int32_t *status_exps, int xe)
 {
     __shared__ float red[3][8];
     __shared__ LayerDyn sd;
     const int h = threadIdx.x;
     const bool act = h < H;
-    const int32_t xlo = act ? (int32_t)(EXT_BIAS - ext[h]) : 0, xhi = act ? (int32_t)(ext[H + h] - EXT_BIAS) : 0;
-    const int xe = a.xe.get();
+    float e0 = 0.f, e1 = 0.f;
+    if (act) {
+        e0 = __hip_atomic_load(ext + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        e1 = __hip_atomic_load(ext + H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int32_t xlo = act ? (int32_t)(EXT_BIAS - e0) : 0, xhi = act ? (int32_t)(e1 - EXT_BIAS) : 0;
     if (h == 0) sd = *d;
     __syncthreads();
     // ---- stage 1: x + (-mean)        fxpmodel.py:892-897
@@ -224,6 +154,138 @@ __global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *e
         for (int i = 0; i < 8; ++i) d->mx[i] = sd.mx[i];
     }
 }
+
+// stand-alone form (multi-rank mode: the extremes are exchanged between the two kernels)
+__global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *ext, int H, LayerDyn *d, int32_t *status,
+                                                        int32_t *status_exps)
+{
+    bn_finalize_mm_body(a, ext, H, d, status, status_exps, a.xe.get());
+}
+
+// Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
+// layer's BatchNorm operand).  RESID=false: extremes of z only (the encoder output ahead of layer 0).
+// block = 256 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes; four frames in flight
+// per thread.  ext == nullptr: no extremes wanted (last layer).
+// Two single-workgroup kernels are folded in (single-rank mode; with a multi-rank hook they stay separate
+// because the ranks exchange maxima in between):
+//   head  the residual add's compute_best exponent (k_res_finalize): every workgroup derives it from the three
+//         maxima, workgroup 0 publishes it;
+//   tail  the NEXT layer's BatchNorm exponents (k_bn_finalize_mm): the workgroup that takes the last ticket
+//         runs it once all extremes are in.  No workgroup ever waits for another.
+struct ResidHead {
+    LayerDyn *d;
+    int32_t res_exp;
+    DynExp skip_e;
+    int32_t redo_slot;
+    int32_t *status_exps;
+    int32_t enable; // 0: d->res was written by k_res_finalize
+};
+struct ResidTail {
+    BnArgs bn; // the next layer's (layer 0's for RESID=false)
+    LayerDyn *d_next;
+    int32_t *status_exps_next;
+    int32_t *ticket; // zeroed with the LayerDyn block
+    int32_t xe_static; // RESID=false: exponent of z
+    int32_t enable;
+};
+
+template <bool RESID>
+__global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
+                                                        int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
+                                                        int res_bits, int skip_bits, ResidHead hd, float *ext, ResidTail tl,
+                                                        int32_t *status)
+{
+    __shared__ int32_t smin[256 * 8], smax[256 * 8];
+    __shared__ AddCb sp;
+    __shared__ int last;
+    const int G = H >> 3, R = 256 / G;
+    const int g = threadIdx.x % G, rl = threadIdx.x / G;
+    AddCb p{};
+    if constexpr (RESID) {
+        if (hd.enable) {
+            if (threadIdx.x == 0) {
+                sp = finalize_add_cb(hd.d->mx + (hd.d->redo ? hd.redo_slot : 8), hd.res_exp, hd.skip_e.get(), res_bits, status);
+                if (blockIdx.x == 0) {
+                    hd.d->res = sp;
+                    hd.status_exps[4] = sp.eo;
+                }
+            }
+            __syncthreads();
+            p = sp;
+        } else {
+            p = hd.d->res;
+        }
+    }
+    int32_t lo[8], hi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        lo[e] = 32767;
+        hi[e] = -32768;
+    }
+    if (rl < R) {
+        const int64_t stride = (int64_t)gridDim.x * R;
+        for (int64_t n0 = (int64_t)blockIdx.x * R + rl; n0 < N; n0 += 4 * stride) {
+            v4i zq[4], sq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t n = n0 + k * stride;
+                if (n < N) {
+                    zq[k] = *reinterpret_cast<const v4i *>(z + n * H + 8 * g);
+                    if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t n = n0 + k * stride;
+                if (n < N) {
+                    int32_t v[8], s[8];
+                    unpack8_i16(zq[k], v);
+                    if constexpr (RESID) {
+                        unpack8_i16(sq[k], s);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
+                            if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
+                            v[e] = rr < 0 ? 0 : rr;
+                        }
+                        const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
+                        *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        lo[e] = v[e] < lo[e] ? v[e] : lo[e];
+                        hi[e] = v[e] > hi[e] ? v[e] : hi[e];
+                    }
+                }
+            }
+        }
+    }
+    if (!ext) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        smin[threadIdx.x * 8 + e] = lo[e];
+        smax[threadIdx.x * 8 + e] = hi[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < H) { // one thread per channel folds the R frame lanes
+        const int c = threadIdx.x;
+        int32_t a = 32767, b = -32768;
+        for (int r = 0; r < R; ++r) {
+            a = min(a, smin[r * G * 8 + c]);
+            b = max(b, smax[r * G * 8 + c]);
+        }
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)a));
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + H + c, __float_as_uint(EXT_BIAS + (float)b));
+    }
+    if (!tl.enable) return;
+    // the extremes are agent-scope atomics; once this workgroup's are acknowledged it takes a ticket
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last) bn_finalize_mm_body(tl.bn, ext, H, tl.d_next, status, tl.status_exps_next, RESID ? p.eo : tl.xe_static);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Lean BatchNorm chain for the MFMA path.  Preconditions (host-checked, the same as for the extremes

@@ -37,6 +37,7 @@ struct CGateArgs {
     DynExp skip_e;
     LayerDyn *dynw;
     int32_t *status;
+    int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
 };
 
 // multi-rank mode only: the residual maxima of a re-run layer live in slots 11..13; move them to 8..10, the
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
     // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
     if (__any(xrange > 2u * (uint32_t)a.xmax) && l == 0) {
         atomicExch(&a.dynw->redo, 1);
-        atomicOr(a.status, ST_WIDE_STATE);
+        atomicOr(a.status, a.bad_bits);
     }
     mx[0] = ldexpf(mx[0], -skip_e);
     mx[1] = ldexpf(mx[1], -a.res_exp);

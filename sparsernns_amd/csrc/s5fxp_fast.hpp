@@ -186,6 +186,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
+    const bool exact = opts && (opts->flags & S5FXP_FWD_EXACT);
+    const bool defer = opts && (opts->flags & S5FXP_FWD_DEFER_REDO) && !exact;
     const FastWs w = fast_ws(m, B, L);
     char *ws = reinterpret_cast<char *>(workspace);
     auto I16 = [&](size_t off) { return reinterpret_cast<int16_t *>(ws + off); };
@@ -236,6 +238,24 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     }
     int hb = m->enc.out_bits;
     DynExp he{m->enc.out_exp, nullptr};
+    // BatchNorm arguments of layer li, whose input has hb_in bits and the (device) exponent he_in
+    auto make_bn = [&](int li, int hb_in, DynExp he_in) {
+        const LayerDev &l = m->layers[li];
+        const s5fxp_ssm_desc &s = l.sd;
+        auto mx = [](int a, int b) { return a > b ? a : b; };
+        BnArgs bn{};
+        bn.mm = l.mm; bn.isv = l.isv; bn.scale = l.scale; bn.bias = l.nbias;
+        bn.xb = hb_in; bn.xe = he_in;
+        bn.mb = l.nd.mean_bits; bn.me = l.nd.mean_exp; bn.b1 = mx(hb_in, bn.mb);
+        bn.ib = l.nd.invsq_var_bits; bn.ie = l.nd.invsq_var_exp; bn.b2 = mx(bn.b1, bn.ib);
+        bn.sb = l.nd.scale_bits; bn.se = l.nd.scale_exp; bn.b3 = l.scale ? mx(bn.b2, bn.sb) : bn.b2;
+        bn.bb = l.nd.bias_bits; bn.be = l.nd.bias_exp; bn.b4 = l.nbias ? mx(bn.b3, bn.bb) : bn.b3;
+        bn.ub = s.u_bits; bn.ue = s.u_exp; bn.out_bits = bn.b4; bn.dyn = dyn + li;
+        return bn;
+    };
+    // single-rank mode folds the two one-workgroup "finalize" kernels of every layer into the residual pass
+    // (mfma_bn.hpp k_resid_minmax16); with a multi-rank hook the maxima are exchanged in between, so they stay
+    const bool fold = bn_ext && !allreduce;
 
     for (int li = 0; li < m->n_layers; ++li) {
         const LayerDev &l = m->layers[li];
@@ -246,14 +266,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const s5fxp_ssm_desc &s = l.sd;
         auto mx = [](int a, int b) { return a > b ? a : b; };
 
-        BnArgs bn{};
-        bn.mm = l.mm; bn.isv = l.isv; bn.scale = l.scale; bn.bias = l.nbias;
-        bn.xb = hb; bn.xe = he;
-        bn.mb = l.nd.mean_bits; bn.me = l.nd.mean_exp; bn.b1 = mx(hb, bn.mb);
-        bn.ib = l.nd.invsq_var_bits; bn.ie = l.nd.invsq_var_exp; bn.b2 = mx(bn.b1, bn.ib);
-        bn.sb = l.nd.scale_bits; bn.se = l.nd.scale_exp; bn.b3 = l.scale ? mx(bn.b2, bn.sb) : bn.b2;
-        bn.bb = l.nd.bias_bits; bn.be = l.nd.bias_exp; bn.b4 = l.nbias ? mx(bn.b3, bn.bb) : bn.b3;
-        bn.ub = s.u_bits; bn.ue = s.u_exp; bn.out_bits = bn.b4; bn.dyn = d;
+        const BnArgs bn = make_bn(li, hb, he);
 
         const unsigned rg = ew_grid(NH / 4) > 2048 ? 2048 : ew_grid(NH / 4);
         auto hook = [&](int slot, int n) -> int {
@@ -262,13 +275,19 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (bn_ext) {
             float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H;
             // layer 0: extremes of the encoder output; later layers: the previous layer's residual pass left them
-            if (li == 0)
+            if (li == 0) {
+                ResidTail tl{};
+                tl.bn = bn; tl.d_next = d; tl.status_exps_next = st_exps; tl.ticket = &d->pad1[0];
+                tl.xe_static = m->enc.out_exp; tl.enable = fold ? 1 : 0;
                 hipLaunchKernelGGL(k_resid_minmax16<false>, dim3(512), dim3(256), 0, st, (const int16_t *)h,
-                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, 0, 0,
-                                   (const LayerDyn *)nullptr, ext);
-            // mode A: the extremes (positive floats) are what the ranks exchange -- one MAX over 2H values
-            if (allreduce && allreduce(allreduce_ctx, ext, 2 * H, (void *)st)) return S5FXP_EHIP;
-            hipLaunchKernelGGL(k_bn_finalize_mm, dim3(1), dim3(256), 0, st, bn, (const float *)ext, H, d, status, st_exps);
+                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, 0, 0, ResidHead{},
+                                   ext, tl, status);
+            }
+            if (!fold) {
+                // mode A: the extremes (positive floats) are what the ranks exchange -- one MAX over 2H values
+                if (allreduce && allreduce(allreduce_ctx, ext, 2 * H, (void *)st)) return S5FXP_EHIP;
+                hipLaunchKernelGGL(k_bn_finalize_mm, dim3(1), dim3(256), 0, st, bn, (const float *)ext, H, d, status, st_exps);
+            }
         } else {
         hipLaunchKernelGGL(k_bn_reduce16<1>, dim3(rg), dim3(256), 0, st, bn, (const int16_t *)h, NH, H, d);
         if (hook(0, 3)) return S5FXP_EHIP;
@@ -317,7 +336,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = 32767; // the C projection's 16-bit planes
         if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
-        if (l.quad_ok) {
+        const bool quad = l.quad_ok && !exact;
+        if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
@@ -361,33 +381,38 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.res_exp = l.res_exp; a.rs_gate = ga.rs_gate; a.skip_e = he; a.dynw = d; a.status = status;
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
+            a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
             const size_t smem = 5 * (size_t)H * 4 + 32 + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
-            if (tr) {
+            if (exact) {
+                // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
+                if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
+            } else if (tr) {
                 if (big) launch6(k_cgate_p<4, 6, true>, smem, a);
                 else launch6(k_cgate_p<2, 3, true>, smem, a);
             } else {
                 if (big) launch6(k_cgate_p<4, 6, false>, smem, a);
                 else launch6(k_cgate_p<2, 3, false>, smem, a);
             }
-            // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo)
-            if (l.quad_ok) {
-                sl.run_if = &d->redo;
-                hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+            // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo); with
+            // S5FXP_FWD_DEFER_REDO the caller repeats the forward instead (S5FXP_ST_REDO)
+            if (!defer) {
+                if (quad) {
+                    sl.run_if = &d->redo;
+                    hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+                }
+                CprojArgs g{};
+                g.bn = bn; g.x = h; g.xs = I32(w.xs); g.w_re = l.c_re_t; g.w_im = l.c_im_t; g.D = l.D;
+                g.x1 = I16(w.x1); g.tr_ys = tr ? tr->ys : nullptr; g.N = N; g.L = L; g.TB = w.TB; g.H = H; g.P = P;
+                g.mw = mw_for(H); g.rs_re = a.rs_re; g.rs_im = a.rs_im; g.rs_d = a.rs_d; g.y_bits = s.y_bits;
+                g.xmax = xmax; g.dynw = d; g.status = status;
+                const unsigned tiles = (unsigned)((N + TN - 1) / TN);
+                S5_DISPATCH_MW_C(g.mw, false, 1, int16_t, tiles, st, g);
+                ga.run_if = &d->redo; // the re-run's gate kernel: maxima in slots 11..13
+                ga.mx_slot = 11;
+                const size_t smem2 = (size_t)ga.w.Np * ga.w.Kp + 2 * (size_t)ga.w.Np * 4 + 32;
+                if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem2, st, ga);
+                else launch_smem(k_out2gate_mfma<3, 3>, grid, smem2, st, ga);
             }
-            CprojArgs g{};
-            g.bn = bn; g.x = h; g.xs = I32(w.xs); g.w_re = l.c_re_t; g.w_im = l.c_im_t; g.D = l.D;
-            g.x1 = I16(w.x1); g.tr_ys = tr ? tr->ys : nullptr; g.N = N; g.L = L; g.TB = w.TB; g.H = H; g.P = P;
-            g.mw = mw_for(H); g.rs_re = a.rs_re; g.rs_im = a.rs_im; g.rs_d = a.rs_d; g.y_bits = s.y_bits;
-            g.xmax = xmax; g.dynw = d; g.status = status;
-            const unsigned tiles = (unsigned)((N + TN - 1) / TN);
-            S5_DISPATCH_MW_C(g.mw, false, 1, int16_t, tiles, st, g);
-            // fused: this gate kernel is the re-run's (maxima in slots 11..13); unfused: it is THE gate kernel and
-            // runs after x1 is final either way
-            ga.run_if = fused ? &d->redo : nullptr;
-            ga.mx_slot = fused ? 11 : 8;
-            const size_t smem2 = (size_t)ga.w.Np * ga.w.Kp + 2 * (size_t)ga.w.Np * 4 + 32;
-            if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem2, st, ga);
-            else launch_smem(k_out2gate_mfma<3, 3>, grid, smem2, st, ga);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);
@@ -397,13 +422,22 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             if (fused) hipLaunchKernelGGL(k_select_maxima, dim3(1), dim3(64), 0, st, d);
             if (hook(8, 3)) return S5FXP_EHIP;
         }
-        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps,
-                           (fused && !allreduce) ? 11 : 8);
+        const int redo_slot = (allreduce || defer) ? 8 : 11; // mode A moved them; deferred: no re-run happened
+        if (!fold)
+            hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps, redo_slot);
         if (bn_ext) {
-            float *ext_next = li + 1 < m->n_layers ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H : nullptr;
+            const bool more = li + 1 < m->n_layers;
+            float *ext_next = more ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H : nullptr;
+            ResidHead hd{};
+            hd.d = d; hd.res_exp = l.res_exp; hd.skip_e = he; hd.redo_slot = redo_slot; hd.status_exps = st_exps;
+            hd.enable = fold ? 1 : 0;
+            ResidTail tl{};
+            if (more && fold) {
+                tl.bn = make_bn(li + 1, l.res_bits, DynExp{0, &d->res.eo});
+                tl.d_next = d + 1; tl.status_exps_next = st_exps + 8; tl.ticket = &(d + 1)->pad1[0]; tl.enable = 1;
+            }
             hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(512), dim3(256), 0, st, (const int16_t *)I16(w.z),
-                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, l.res_bits, hb, (const LayerDyn *)d,
-                               ext_next);
+                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, l.res_bits, hb, hd, ext_next, tl, status);
         } else {
             hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z),
                                (const int16_t *)h, hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_bn_reduce(BnArgs a, const int32_t *__re
     }
 }
 
-enum { ST_NEGSHIFT = 1, ST_NEGEXP = 2, ST_WIDE_STATE = 4, ST_WIDE_INPUT = 8 };
+enum { ST_NEGSHIFT = 1, ST_NEGEXP = 2, ST_WIDE_STATE = 4, ST_WIDE_INPUT = 8, ST_REDO = 16 };
 
 __device__ inline AddCb finalize_add_cb(const uint32_t *mx, int xe, int ye, int ob, int32_t *status)
 {

@@ -124,8 +124,11 @@ class Engine:
 
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
                 traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
-                scan_events: Optional[list] = None) -> None:
-        """Launches one forward on the current stream; nothing is synchronised."""
+                scan_events: Optional[list] = None, flags: int = 0) -> None:
+        """Launches one forward on the current stream; nothing is synchronised.
+
+        flags: _lib.FWD_DEFER_REDO drops the (normally idle) gated exact re-run launches -- the caller must then
+        read the status words and repeat with _lib.FWD_EXACT when ST_REDO is set (``forward`` does)."""
         ws = self.workspace(B, L)
         tr = None
         if traces is not None:
@@ -154,6 +157,7 @@ class Engine:
             arr = (C.c_void_p * len(scan_events))(*[(e.cuda_event if e is not None else None) for e in scan_events])
             opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
             self._ev_keep = arr
+        opts.flags = int(flags)
         self._cb_keep = opts
         check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
                                       ws.numel(), self.status.data_ptr(),
@@ -195,8 +199,15 @@ class Engine:
                     w = self.P if k in ("Bu_re", "Bu_im", "xs_re", "xs_im") else self.H
                     d[k] = torch.empty(tuple(data.shape[:-1]) + (w,), dtype=torch.int32, device=data.device)
                 tr.append(d)
-        self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce)
-        if check_status:
-            self.check_status()
+        if not check_status:
+            self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce)  # self-contained: exact re-run enqueued, gated
+        else:
+            # the status words are read anyway: run optimistically and repeat with the exact kernels if a state
+            # left the fast recurrence's range (never with a multi-rank hook: ranks must enqueue the same work)
+            self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=0 if allreduce else _lib.FWD_DEFER_REDO)
+            st = self.check_status()
+            if st[0] & _lib.ST_REDO:
+                self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=_lib.FWD_EXACT)
+                self.check_status()
         out = FxpArray(y, self.out_bits, self.out_exp, True)
         return (out, tr) if traces else out

@@ -289,9 +289,20 @@ def test_state_overflow_takes_the_exact_fallback():
     assert max(int(np.abs(t["xs_re"]).max()) for t in rtr) > 32767, "the case must overflow 16 bits to mean anything"
     eng = model.engine()
     assert _lib.lib.s5fxp_model_is_fast(eng._h) == 1
-    y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))
-    assert int(eng.status[0].item()) & _lib.ST_WIDE_STATE
+    fxa = FxpArray(fx.data, fx.bits, fx.exp)
+    # self-contained forward: the gated exact kernels are enqueued with it and fire on the device
+    y = eng.forward(fxa, check_status=False)
     assert np.array_equal(y.numpy(), ref)
+    assert int(eng.status[0].item()) & _lib.ST_WIDE_STATE and not int(eng.status[0].item()) & _lib.ST_REDO
+    # optimistic forward (the default of Engine.forward): ST_REDO comes back, the exact kernels run in a second call
+    import torch
+    y2 = torch.empty_like(y.data)
+    eng.enqueue(fxa.data, fx.bits, fx.exp, y2, 2, 512, flags=_lib.FWD_DEFER_REDO)
+    assert int(eng.status[0].item()) & _lib.ST_REDO
+    eng.enqueue(fxa.data, fx.bits, fx.exp, y2, 2, 512, flags=_lib.FWD_EXACT)
+    assert not int(eng.status[0].item()) & _lib.ST_REDO
+    assert np.array_equal(y2.cpu().numpy(), ref)
+    assert np.array_equal(eng.forward(fxa).numpy(), ref)
     # and the all-generic engine agrees as well
     gen = build_regression_model(md, qc, dims["n_layers"], engine_flags=_lib.MODEL_FORCE_GENERIC)
     assert _lib.lib.s5fxp_model_is_fast(gen.engine()._h) == 0
