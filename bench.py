@@ -29,6 +29,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(B, L, P):
+    """HBM bytes per recurrence launch from the committed PMC passes (profiles/r01_scan_traffic.json: FETCH_SIZE
+    doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), if they were taken on this workload."""
+    p = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        t = json.load(f)
+    return t["traffic_bytes_per_launch"] if (t["B"], t["L"], t["P"]) == (B, L, P) else None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +54,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="sequences in the bounded CPU-baseline sample")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
+    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (streams); 1 = one forward at a time")
     ap.add_argument("--self-contained", action="store_true",
                     help="enqueue the gated exact re-run kernels with every forward (no status check needed)")
     args = ap.parse_args()
@@ -82,45 +94,93 @@ def main() -> None:
         allreduce = make_exponent_allreduce()
     model = build_regression_model(md, qc, dims["n_layers"])
     eng = model.engine()
-    x = synth.make_input(B, L, dims["d_in"], seed=1000 + rank)  # every rank its own batch
-    fx = fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
-                     round_mode=RoundingMode.FLOOR)
-    xin = fx.data
-    y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device=dev)
+    # `inflight` batches are kept in flight, each on its own HIP stream and engine lane (engine.InflightRunner): the
+    # recurrence of one batch (a latency chain on B*P/16 waves) overlaps the projections of the others.  Every lane
+    # has its own resident input and output; a step = one forward over one batch, as before.
+    depth = 1 if (allreduce or args.self_contained) else max(1, args.inflight)
+    from sparsernns_amd.engine import InflightRunner
+    fxs, ys = [], []
+    for lane in range(depth):
+        x = synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane)  # every rank / lane its own batch
+        fxs.append(fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
+                               round_mode=RoundingMode.FLOOR))
+        ys.append(torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device=dev))
+    fx, y = fxs[0], ys[0]
     n_ev = 2 * dims["n_layers"]
+    nl = dims["n_layers"]
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # optimistic mode: the gated exact re-run launches are dropped; the status words checked after the timed
-    # region must not carry ST_REDO (else every step is invalid and the run aborts)
-    fwd_flags = 0 if (allreduce or args.self_contained) else _lib.FWD_DEFER_REDO
-    for _ in range(max(args.warmup, 0)):
-        eng.enqueue(xin, fx.bits, fx.exp, y, B, L, None, allreduce, flags=fwd_flags)
+    def make_events(steps):
+        # one layer's recurrence is bracketed by HIP events per step (rotating over the layers): an event record
+        # costs ~6 us of stream time, so bracketing every layer would inflate the step it measures
+        events = [[None] * n_ev for _ in range(steps)]
+        for k, evs in enumerate(events):
+            for j in (2 * (k % nl), 2 * (k % nl) + 1):
+                evs[j] = torch.cuda.Event(enable_timing=True)
+                evs[j].record()  # torch creates the hipEvent lazily on the first record(); the C side needs the handle
+        return events
+
+    def scan_avg(events):
+        ms = [events[k][2 * (k % nl)].elapsed_time(events[k][2 * (k % nl) + 1]) for k in range(len(events))]
+        return float(np.mean(ms)) * 1e-3
+
+    def run(steps, d, events=None):
+        """`steps` forwards with d batches in flight.  d > 1: optimistic mode (the gated exact re-run launches are
+        dropped); the status words of every lane are checked afterwards and must not carry ST_REDO."""
+        if d == 1:
+            flags = 0 if (allreduce or args.self_contained) else _lib.FWD_DEFER_REDO
+            for k in range(steps):
+                eng.enqueue(fx.data, fx.bits, fx.exp, y, B, L, None, allreduce, flags=flags,
+                            scan_events=events[k] if events else None)
+            return None
+        runner = InflightRunner(eng, d) if run.runner is None else run.runner
+        run.runner = runner
+        for k in range(steps):
+            lane = k % d
+            runner.submit(fxs[lane].data, fxs[lane].bits, fxs[lane].exp, ys[lane], B, L, check=False,
+                          scan_events=events[k] if events else None)
+        return runner
+
+    run.runner = None
+
+    def check_all(d):
+        bits = 0
+        for lane in range(d):
+            bits |= int(eng.check_status(lane)[0])
+        if bits & _lib.ST_REDO:
+            raise SystemExit("a state left the fast recurrence's exact range: the timed steps are invalid; "
+                             "re-run with --self-contained")
+        return bits
+
+    run(max(args.warmup, 0), depth)
     torch.cuda.synchronize()
-    eng.check_status()
+    check_all(depth)
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    # one layer's recurrence is bracketed by HIP events per step (rotating over the layers): an event record costs
-    # ~6 us of stream time, so bracketing every layer would inflate the step it measures
-    nl = dims["n_layers"]
-    events = [[None] * n_ev for _ in range(args.steps)]
-    for k, evs in enumerate(events):
-        for j in (2 * (k % nl), 2 * (k % nl) + 1):
-            evs[j] = torch.cuda.Event(enable_timing=True)
-            evs[j].record()  # torch creates the hipEvent lazily on the first record(); the C side needs the handle
+    events = make_events(args.steps)
     sync_all()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        eng.enqueue(xin, fx.bits, fx.exp, y, B, L, None, allreduce, scan_events=events[k], flags=fwd_flags)
+    run(args.steps, depth, events)
     sync_all()
     dt = time.perf_counter() - t0
-    st = eng.check_status()
-    if st[0] & _lib.ST_REDO:
-        raise SystemExit("a state left the fast recurrence's exact range: the timed steps are invalid; "
-                         "re-run with --self-contained")
+    st0 = check_all(depth)
+
+    # ---- the same K steps one at a time (no overlap between batches), for reference; not the headline
+    single = None
+    if depth > 1:
+        ev1 = make_events(args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(args.steps, 1, ev1)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        check_all(1)
+        single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 4), value=round(B * L * args.steps / dt1, 1),
+                      scan_avg_kernel_us=round(scan_avg(ev1) * 1e6, 2))
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -130,12 +190,11 @@ def main() -> None:
     value = frames / dt
 
     # ---- roofline of the dominant kernel (the recurrence): algorithmic bytes = 16*P per frame per layer
-    scan_ms = [events[k][2 * (k % nl)].elapsed_time(events[k][2 * (k % nl) + 1]) for k in range(args.steps)]
-    scan_avg_s = float(np.mean(scan_ms)) * 1e-3
+    scan_avg_s = scan_avg(events)
     algo_bytes = B * L * dims["P"] * 16
     achieved = algo_bytes / scan_avg_s / 1e9
     roofline = dict(bound="hbm", kernel="scan", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(B, L, dims["P"]),
                     avg_kernel_us=round(scan_avg_s * 1e6, 2), algorithmic_bytes_per_launch=algo_bytes)
 
     # ---- RCCL output gather, exercised once outside the timed region
@@ -175,8 +234,9 @@ def main() -> None:
                                  f"{'dense' if args.sparsity == 0 else f'{args.sparsity:.0%} sparse'} S5, "
                                  f"B={B} x L={L} per GPU, H={dims['H']}, P={dims['P']}, 3 layers, d_in=d_out=257",
                         batch_per_gpu=B, seq_len=L, exponent_mode="global (all-reduce MAX)" if allreduce else "per-shard",
-                        parallelism=f"batch-sharded x{world}"),
-            roofline=roofline, cpu_baseline=cpu, status_bits=int(st[0]), output_gather_ms=gather_ms)
+                        parallelism=f"batch-sharded x{world}", batches_in_flight=depth),
+            roofline=roofline, cpu_baseline=cpu, single_stream=single, status_bits=int(st0),
+            output_gather_ms=gather_ms)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -361,6 +361,7 @@ struct BprojM2Args {
     int64_t N;
     int32_t L, TB, H, P;
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
+    int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
 };
 
 template <int KS, int NT, bool TRACE>

@@ -38,6 +38,7 @@ struct CGateArgs {
     LayerDyn *dynw;
     int32_t *status;
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
+    int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
 };
 
 // multi-rank mode only: the residual maxima of a re-run layer live in slots 11..13; move them to 8..10, the
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
-    const int64_t tiles = (a.N + FT - 1) / FT;
+    const StepRange sr{a.t_lo, a.t_len};
+    const int64_t tiles = (a.N / a.L) * ((sr.t_len + FT - 1) / FT);
 
     // weights of this wave's 32 channels (A operand rows), all k-steps, in registers
     v4i wre[KS], wim[KS], wo2[NT];
@@ -305,16 +307,17 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
     __syncthreads();
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t n0 = tile * FT;
-        const int64_t b0 = n0 / a.L;
-        const int t0 = (int)(n0 - b0 * a.L);
-        const bool nowrap = t0 + FT <= a.L;
+        int64_t b0;
+        int t0, nvalid;
+        tile_of(tile, sr, b0, t0, nvalid);
+        const int64_t n0 = b0 * a.L + t0;
         // ---- u and skip of this wave's units: requested first, consumed in the epilogues
         v2i uq[NU][4], sq[NU][4];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            int64_t n = n0 + 32 * (sub0 + u * SUBSTEP) + r;
-            n = n < a.N ? n : a.N - 1;
+            int fo = 32 * (sub0 + u * SUBSTEP) + r;
+            fo = fo < nvalid ? fo : nvalid - 1;
+            const int64_t n = n0 + fo;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uq[u][g] = *reinterpret_cast<const v2i *>(a.u + n * H + ch0 + 8 * g);
@@ -328,11 +331,8 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
             if (ROUNDS * 384 == ITEMS || q < ITEMS) {
                 const int grp = q / P, p = q % P;
                 int o = 4 * grp;
-                if (n0 + o >= a.N) o = (int)(a.N - 4 - n0); // partial tile: re-read the last block (results unused)
-                int64_t b;
-                int t;
-                frame_bt(b0, t0, o, a.L, nowrap, b, t);
-                const int32_t *src = a.xs + native_word(b, t, p, 0, a.TB, P);
+                if (o >= nvalid) o = nvalid - 4; // partial tile: re-read the last block (results unused)
+                const int32_t *src = a.xs + native_word(b0, t0 + o, p, 0, a.TB, P);
                 const v4i cre = *reinterpret_cast<const v4i *>(src), cim = *reinterpret_cast<const v4i *>(src + 4);
                 int32_t w[4];
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
                     const int32_t du = sat(asr(__mul24(Dv[e], uv[e]), a.rs_d), a.y_bits);
                     const int32_t y = sat(2 * cx + du, a.y_bits); // 2*cx is not clipped, fxpmodel.py:765-767
                     if (TRACE) {
-                        if (a.tr_ys && n < a.N) a.tr_ys[n * H + ch0 + 8 * g + e] = y;
+                        if (a.tr_ys && 32 * sub + r < nvalid) a.tr_ys[n * H + ch0 + 8 * g + e] = y;
                     }
                     const int32_t x1 = y < 0 ? 0 : y;
                     x1v[u][4 * g + e] = x1;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
             const int64_t n = n0 + 32 * sub + r;
             v16i acc;
             mfma_planes<NT>(acc, wo2, Xh + (32 * sub + r) * KPX + 16 * h, Xl + (32 * sub + r) * KPX + 16 * h, cs2 + ch0);
-            if (n < a.N) {
+            if (32 * sub + r < nvalid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = ch0 + 8 * g;

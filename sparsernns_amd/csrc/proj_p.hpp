@@ -31,16 +31,18 @@ __device__ __forceinline__ void planes8_from_i32(const int32_t (&v)[8], v2i &hi,
     }
 }
 
-// (sequence, step) of frame n0 + o for a small offset o; b0/t0 belong to n0.  Division only when the tile
-// crosses a sequence boundary.
-__device__ __forceinline__ void frame_bt(int64_t b0, int t0, int o, int L, bool nowrap, int64_t &b, int &t)
+// Tiles of the per-layer kernels are 64 steps of ONE sequence inside a step range [t_lo, t_lo + t_len) (the
+// whole sequence, or one chunk of the bproj | scan | cgate pipeline): tile -> (sequence, first step, valid steps)
+struct StepRange {
+    int32_t t_lo, t_len; // multiples of 4 (t_lo: of 64)
+};
+__device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64_t &b, int &t, int &nvalid)
 {
-    t = t0 + o;
-    b = b0;
-    if (!nowrap) {
-        b += t / L;
-        t = t % L;
-    }
+    const int tps = (sr.t_len + 63) >> 6;
+    b = tile / tps;
+    const int tt = (int)(tile - b * tps) << 6;
+    t = sr.t_lo + tt;
+    nvalid = sr.t_len - tt < 64 ? sr.t_len - tt : 64;
 }
 
 template <int KS, int NT, bool TRACE>
@@ -56,17 +58,21 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
     int32_t *tab = reinterpret_cast<int32_t *>(smem);             // 4*H BatchNorm operands
     int8_t *Xh = smem + 16 * H, *Xl = Xh + 2 * PLANE;             // [buf][frame][KP]
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + FT - 1) / FT;
+    const StepRange sr{a.t_lo, a.t_len};
+    const int64_t tiles = (a.N / a.L) * ((sr.t_len + FT - 1) / FT);
     int64_t tile = blockIdx.x;
 
     v4i raw[NV];
     auto fetch = [&](int64_t tl) {
+        int64_t b;
+        int t, nv;
+        tile_of(tl, sr, b, t, nv);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = threadIdx.x + 256 * i;
-            int64_t n = tl * FT + v / VPF;
-            n = n < a.N ? n : a.N - 1;
-            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * H + 8 * (v % VPF));
+            int f = v / VPF;
+            f = f < nv ? f : nv - 1;
+            raw[i] = *reinterpret_cast<const v4i *>(a.x + (b * a.L + t + f) * H + 8 * (v % VPF));
         }
     };
     if (tile < tiles) fetch(tile);
@@ -86,7 +92,10 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
     __syncthreads();
 
     for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-        const int64_t n0 = tile * FT;
+        int64_t b0;
+        int t0, nvalid;
+        tile_of(tile, sr, b0, t0, nvalid);
+        const int64_t n0 = b0 * a.L + t0;
         int8_t *xh = Xh + (it & 1) * PLANE, *xl = Xl + (it & 1) * PLANE;
         // ---- phase A: BatchNorm chain, u, byte planes
 #pragma unroll
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
                     reinterpret_cast<int32_t(&)[4]>(u[0]));
             bn16_x4(bn, reinterpret_cast<const int32_t(&)[4]>(xin[4]), 8 * og + 4, reinterpret_cast<int32_t(&)[4]>(t[4]),
                     reinterpret_cast<int32_t(&)[4]>(u[4]));
-            if (n < a.N) {
+            if (f < nvalid) {
                 const v2i p0 = pack4_i16(u[0], u[1], u[2], u[3]), p1 = pack4_i16(u[4], u[5], u[6], u[7]);
                 *reinterpret_cast<v4i *>(a.u + n * H + 8 * og) = v4i{p0[0], p0[1], p1[0], p1[1]};
                 if (TRACE) {
@@ -118,9 +127,6 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
         if (tile + gridDim.x < tiles) fetch(tile + gridDim.x); // in flight during phase B
         __syncthreads();
         // ---- phase B: this wave's column tile(s), both 32-frame halves
-        const int64_t b0 = n0 / a.L;
-        const int t0 = (int)(n0 - b0 * a.L);
-        const bool nowrap = t0 + FT <= a.L;
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
             const int col = 32 * (wave + 4 * c) + r;
@@ -145,10 +151,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int o = 32 * sub + 8 * g + 4 * h;
-                    if (n0 + o < a.N) {
-                        int64_t b;
-                        int t;
-                        frame_bt(b0, t0, o, a.L, nowrap, b, t);
+                    if (o < nvalid) {
                         v4i q;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }
                         }
-                        *reinterpret_cast<v4i *>(a.bq + native_word(b, t, p, cc, a.TB, PC)) = q;
+                        *reinterpret_cast<v4i *>(a.bq + native_word(b0, t0 + o, p, cc, a.TB, PC)) = q;
                     }
                 }
             }

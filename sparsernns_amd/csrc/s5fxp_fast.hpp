@@ -15,9 +15,43 @@ struct FastLayer {
     const int32_t *Dpad = nullptr; // [Np]
 };
 
+// The recurrence keeps only B*P/16 waves busy for ~50 us per layer while the projections on either side of it
+// want the whole chip: each layer's bproj | scan | cgate sequence is cut into step chunks, the scan chunks run
+// on a side stream (created with the model, highest priority) and overlap the projections of their neighbours.
+constexpr int MAX_CHUNKS = 8;
+struct Pipeline {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_b[MAX_CHUNKS] = {}, ev_s[MAX_CHUNKS] = {};
+    bool ok = false, tried = false;
+    int chunks = 1; // measured (profiles/r01_pipeline_chunks.txt): cross-queue waits cost 12-22 us per hop, 2 chunks are 10 % slower
+    void init()
+    {
+        tried = true;
+        if (const char *e = std::getenv("S5FXP_CHUNKS")) chunks = std::atoi(e);
+        if (chunks < 2 || chunks > MAX_CHUNKS) return; // 1 (default): no pipelining; S5FXP_CHUNKS=2..8 to experiment
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest) != hipSuccess) { side = nullptr; return; }
+        for (int i = 0; i < MAX_CHUNKS; ++i)
+            if (hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_s[i], hipEventDisableTiming) != hipSuccess)
+                return;
+        ok = true;
+    }
+    ~Pipeline()
+    {
+        for (int i = 0; i < MAX_CHUNKS; ++i) {
+            if (ev_b[i]) (void)hipEventDestroy(ev_b[i]);
+            if (ev_s[i]) (void)hipEventDestroy(ev_s[i]);
+        }
+        if (side) (void)hipStreamDestroy(side);
+    }
+};
+
 struct FastModel {
     MfmaWDev enc, dec;
     std::vector<FastLayer> layers;
+    mutable Pipeline pipe; // one forward at a time per model handle
 };
 
 namespace {
@@ -215,11 +249,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles, two workgroups per CU
     const int64_t tiles64 = (N + 63) / 64, per6 = (tiles64 + 511) / 512;
     const unsigned grid6 = (unsigned)((tiles64 + per6 - 1) / per6);
-    auto launch6 = [&](auto kernel, size_t smem, const auto &args) {
+    auto launch6g = [&](auto kernel, unsigned g6, size_t smem, const auto &args) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kernel, dim3(grid6), dim3(384), smem, st, args);
+        hipLaunchKernelGGL(kernel, dim3(g6), dim3(384), smem, st, args);
     };
+    auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid6, smem, args); };
 
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
     // ---- encoder + ReLU
@@ -253,6 +288,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         bn.ub = s.u_bits; bn.ue = s.u_exp; bn.out_bits = bn.b4; bn.dyn = dyn + li;
         return bn;
     };
+    // step chunks of the bproj | scan | cgate pipeline (see Pipeline): multiples of 64 steps, the last takes the rest
+    int n_chunks = 1, c_lo[MAX_CHUNKS + 1] = {0, L};
+    if (!exact && !traces && !allreduce) {
+        if (!F.pipe.tried) F.pipe.init();
+        const int base = (L / (F.pipe.chunks > 0 ? F.pipe.chunks : 1)) / 64 * 64;
+        if (F.pipe.ok && base >= 256) {
+            n_chunks = F.pipe.chunks;
+            for (int k = 0; k < n_chunks; ++k) c_lo[k] = k * base;
+            c_lo[n_chunks] = L;
+        }
+    }
     // single-rank mode folds the two one-workgroup "finalize" kernels of every layer into the residual pass
     // (mfma_bn.hpp k_resid_minmax16); with a multi-rank hook the maxima are exchanged in between, so they stay
     const bool fold = bn_ext && !allreduce;
@@ -317,16 +363,20 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
-            // phase-split kernel (proj_p.hpp): 64-frame tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
-            const int64_t tiles64 = (N + 63) / 64, cap = big ? 512 : 1024, per = (tiles64 + cap - 1) / cap;
-            const unsigned pgrid = (unsigned)((tiles64 + per - 1) / per);
+            // phase-split kernel (proj_p.hpp): 64-step tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
-            if (tr) {
-                if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a);
-                else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a);
-            } else {
-                if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a);
-                else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a);
+            for (int k = 0; k < n_chunks; ++k) {
+                a.t_lo = c_lo[k]; a.t_len = c_lo[k + 1] - c_lo[k];
+                const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? 512 : 1024, per = (tl + cap - 1) / cap;
+                const unsigned pgrid = (unsigned)((tl + per - 1) / per);
+                if (tr) {
+                    if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a);
+                    else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a);
+                } else {
+                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a);
+                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a);
+                }
+                if (n_chunks > 1 && (rc = hip_rc(hipEventRecord(F.pipe.ev_b[k], st)))) return rc;
             }
         }
         // ---- recurrence
@@ -335,19 +385,30 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = 32767; // the C projection's 16-bit planes
-        if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], st)))) return rc;
         const bool quad = l.quad_ok && !exact;
+        const bool piped = quad && n_chunks > 1;
+        hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
+        if (piped && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[0], 0)))) return rc;
+        if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], sst)))) return rc;
         if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
-            hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+            for (int k = 0; k < (piped ? n_chunks : 1); ++k) {
+                if (piped) {
+                    if (k > 0 && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[k], 0)))) return rc;
+                    q.tb0 = c_lo[k] / 4;
+                    q.ntb = k + 1 < n_chunks ? (c_lo[k + 1] - c_lo[k]) / 4 : 0; // the last chunk runs to the padded end
+                }
+                hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
+                if (piped && (rc = hip_rc(hipEventRecord(F.pipe.ev_s[k], sst)))) return rc;
+            }
             xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
         } else {
             sl.run_if = nullptr;
             hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
         }
-        if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], st)))) return rc;
+        if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], sst)))) return rc;
         // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
         GateMArgs ga{};
         bool fused = false;
@@ -386,12 +447,21 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
-            } else if (tr) {
-                if (big) launch6(k_cgate_p<4, 6, true>, smem, a);
-                else launch6(k_cgate_p<2, 3, true>, smem, a);
             } else {
-                if (big) launch6(k_cgate_p<4, 6, false>, smem, a);
-                else launch6(k_cgate_p<2, 3, false>, smem, a);
+                const int nck = piped ? n_chunks : 1;
+                for (int k = 0; k < nck; ++k) {
+                    a.t_lo = piped ? c_lo[k] : 0; a.t_len = piped ? c_lo[k + 1] - c_lo[k] : L;
+                    if (piped && (rc = hip_rc(hipStreamWaitEvent(st, F.pipe.ev_s[k], 0)))) return rc;
+                    const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + 511) / 512;
+                    const unsigned cg = (unsigned)((tl + per - 1) / per);
+                    if (tr) {
+                        if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a);
+                        else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
+                    } else {
+                        if (big) launch6g(k_cgate_p<4, 6, false>, cg, smem, a);
+                        else launch6g(k_cgate_p<2, 3, false>, cg, smem, a);
+                    }
+                }
             }
             // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo); with
             // S5FXP_FWD_DEFER_REDO the caller repeats the forward instead (S5FXP_ST_REDO)

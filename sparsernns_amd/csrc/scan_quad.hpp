@@ -48,6 +48,7 @@ struct ScanQuadArgs {
     const int32_t *a_re, *a_im; // (P)
     int32_t B, TB, P;           // TB = number of 4-step time blocks per sequence (stream extent)
     int32_t ea_re, ea_im;
+    int32_t tb0, ntb;           // k_scan_quad_asm: first time block and block count of this launch (0, 0 = all)
 };
 
 // PRE is "s_nop 1\n\t" for the first step after a 16-byte buffer_store: gfx940+ needs 2 wait states
@@ -144,18 +145,24 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
     else if (r == 1) { cA = cB = Ar << sim; }
     else if (r == 2) { cA = -(Ai << sre); kA = kre; cB = Ai << sim; }
     else { cA = Ai << sim; cB = -(Ai << sre); kB = kre; }
-    const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // words
+    // this launch covers time blocks [tb0, tb0 + ntb) (ntb % DEPTH == 0; ntb == 0: up to TB): a chunk of the
+    // bproj | scan | cgate pipeline starts from the last state of the previous chunk.  After an odd step lanes
+    // 0,3 of a quad hold the real part and lanes 1,2 the imaginary part.
+    const int tb0 = a.tb0, ntb = a.ntb > 0 ? a.ntb : a.TB - a.tb0;
+    int32_t x0 = 0;
+    if (tb0 > 0) x0 = a.xs[native_word(b, 4 * tb0 - 1, p, (r == 0 || r == 3) ? 0 : 1, a.TB, a.P)];
+    const size_t wave_off = (((size_t)b * a.TB + tb0) * a.P + p0) * 8; // words
     const unsigned blk_stride = (unsigned)a.P * 32u;
-    const unsigned extent = (unsigned)a.TB * blk_stride;
+    const unsigned extent = (unsigned)(a.TB - tb0) * blk_stride;
     const unsigned long long bin = (unsigned long long)(a.bq + wave_off), bout = (unsigned long long)(a.xs + wave_off);
     u32x4 rin, rout;
     rin[0] = (unsigned)bin; rin[1] = (unsigned)(bin >> 32) & 0xffffu; rin[2] = extent; rin[3] = 0x00020000u;
     rout[0] = (unsigned)bout; rout[1] = (unsigned)(bout >> 32) & 0xffffu; rout[2] = extent; rout[3] = 0x00020000u;
     const unsigned voff = r < 2 ? (unsigned)(s * 32 + r * 16) : 0xFFFFFF00u;
-    unsigned sld = 0, sst = 0, cnt = (unsigned)a.TB / S5_SCAN_ASM_DEPTH;
+    unsigned sld = 0, sst = 0, cnt = (unsigned)ntb / S5_SCAN_ASM_DEPTH;
     asm volatile(S5_SCAN_ASM_BODY
                  : [sld] "+s"(sld), [sst] "+s"(sst), [cnt] "+s"(cnt)
-                 : [ca] "v"(cA), [cb] "v"(cB), [ka] "v"(kA), [kb] "v"(kB), [voff] "v"(voff), [rin] "s"(rin),
+                 : [ca] "v"(cA), [cb] "v"(cB), [ka] "v"(kA), [kb] "v"(kB), [voff] "v"(voff), [x0] "v"(x0), [rin] "s"(rin),
                    [rout] "s"(rout), [stride] "s"(blk_stride)
                  : S5_SCAN_ASM_CLOBBERS);
 }

@@ -52,9 +52,10 @@ class Engine:
                                          torch.cuda.current_stream().cuda_stream, C.byref(handle)), "s5fxp_model_create")
         self._h = handle
         self.out_bits, self.out_exp = lib.s5fxp_model_out_bits(self._h), lib.s5fxp_model_out_exp(self._h)
-        self.status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)
-        self._ws: Optional[torch.Tensor] = None
-        self._ws_key = None
+        # a lane = the per-forward mutable state (status words + workspace); forwards on different lanes may be
+        # in flight at the same time on different streams (InflightRunner).  Lane 0 is the default.
+        self._status = {0: torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)}
+        self._wsl: Dict[int, tuple] = {}
         self._cb_keep = None
 
     def __del__(self):
@@ -114,22 +115,31 @@ class Engine:
             L.lut[j] = int(lut[j])
 
     # -- forward ---------------------------------------------------------------------------------
-    def workspace(self, B: int, L: int) -> torch.Tensor:
-        key = (B, L)
-        if self._ws_key != key:
+    @property
+    def status(self) -> torch.Tensor:
+        return self._status[0]
+
+    def lane_status(self, lane: int) -> torch.Tensor:
+        if lane not in self._status:
+            self._status[lane] = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)
+        return self._status[lane]
+
+    def workspace(self, B: int, L: int, lane: int = 0) -> torch.Tensor:
+        key, ws = self._wsl.get(lane, (None, None))
+        if key != (B, L):
             n = lib.s5fxp_workspace_bytes(self._h, B, L)
-            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._ws_key = key
-        return self._ws
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._wsl[lane] = ((B, L), ws)
+        return ws
 
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
                 traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
-                scan_events: Optional[list] = None, flags: int = 0) -> None:
+                scan_events: Optional[list] = None, flags: int = 0, lane: int = 0) -> None:
         """Launches one forward on the current stream; nothing is synchronised.
 
         flags: _lib.FWD_DEFER_REDO drops the (normally idle) gated exact re-run launches -- the caller must then
         read the status words and repeat with _lib.FWD_EXACT when ST_REDO is set (``forward`` does)."""
-        ws = self.workspace(B, L)
+        ws = self.workspace(B, L, lane)
         tr = None
         if traces is not None:
             tr = (LayerTrace * self.n_layers)()
@@ -160,13 +170,13 @@ class Engine:
         opts.flags = int(flags)
         self._cb_keep = opts
         check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), self.status.data_ptr(),
+                                      ws.numel(), self.lane_status(lane).data_ptr(),
                                       C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, C.byref(opts),
                                       torch.cuda.current_stream().cuda_stream), "s5fxp_model_forward")
 
-    def check_status(self) -> np.ndarray:
+    def check_status(self, lane: int = 0) -> np.ndarray:
         """Reads the status words back (one sync) and raises what the reference would have raised."""
-        st = self.status.cpu().numpy()
+        st = self.lane_status(lane).cpu().numpy()
         if st[0] & _lib.ST_NEGSHIFT:
             raise ValueError("invalid result_exp: a data-dependent shift came out negative (fxparray.py:619-621)")
         if st[0] & _lib.ST_NEGEXP:
@@ -211,3 +221,58 @@ class Engine:
                 self.check_status()
         out = FxpArray(y, self.out_bits, self.out_exp, True)
         return (out, tr) if traces else out
+
+
+class InflightRunner:
+    """Keeps up to ``depth`` forwards of one Engine in flight, each on its own HIP stream and lane.
+
+    One layer's recurrence is a latency chain that occupies B*P/16 waves; the projections around it want the
+    whole chip.  Within one forward they cannot overlap (every layer's exponents depend on the whole previous
+    layer), but the recurrence of one batch overlaps the projections of the others.  Batches are independent,
+    so the results are the ones ``Engine.forward`` gives.
+
+    submit() returns at once; a lane is synchronised and its status words are checked (with the exact re-run if
+    ST_REDO came back) when the lane is reused or on drain().
+    """
+
+    def __init__(self, engine: Engine, depth: int = 3):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.engine, self.depth = engine, depth
+        self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
+        self._pending: List[Optional[tuple]] = [None] * depth
+        self._next = 0
+
+    def submit(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int, check: bool = True,
+               scan_events: Optional[list] = None) -> int:
+        """check=False skips the status check of the lane's previous batch (only sound when every batch of the lane
+        is the same input, as in bench.py: the last check then speaks for all)."""
+        lane = self._next
+        self._next = (lane + 1) % self.depth
+        if check:
+            self._finish(lane)
+        s = self.streams[lane]
+        s.wait_stream(torch.cuda.current_stream(self.engine.device))
+        with torch.cuda.stream(s):
+            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_DEFER_REDO, lane=lane, scan_events=scan_events)
+        self._pending[lane] = (x, x_bits, x_exp, y, B, L)
+        return lane
+
+    def _finish(self, lane: int) -> None:
+        job = self._pending[lane]
+        if job is None:
+            return
+        self._pending[lane] = None
+        s = self.streams[lane]
+        s.synchronize()
+        st = self.engine.check_status(lane)
+        if st[0] & _lib.ST_REDO:
+            x, x_bits, x_exp, y, B, L = job
+            with torch.cuda.stream(s):
+                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_EXACT, lane=lane)
+            s.synchronize()
+            self.engine.check_status(lane)
+
+    def drain(self) -> None:
+        for lane in range(self.depth):
+            self._finish(lane)

@@ -345,3 +345,29 @@ def test_exponent_hook_is_called_per_compute_best_op():
     # per layer: the per-channel extremes the BatchNorm exponents are derived from (2H floats), then the
     # three maxima of the residual add
     assert calls == [2 * dims["H"], 3] * dims["n_layers"]
+
+
+def test_inflight_runner_matches_oracle_per_batch():
+    """Several different batches kept in flight on separate streams / lanes of one engine: every output must be
+    the oracle's for ITS batch (no cross-talk between lanes), including a batch that needs the exact re-run."""
+    import torch
+    from sparsernns_amd.engine import InflightRunner
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    B, L = 2, 256
+    runner = InflightRunner(eng, depth=3)
+    jobs = []
+    for i in range(7):
+        fx = _input(qc, dims, B, L, seed=40 + i, scale=6.0 if i == 4 else 1.0)  # batch 4 overflows the fast range
+        x = torch.from_numpy(fx.data).cuda()
+        y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+        runner.submit(x, fx.bits, fx.exp, y, B, L)
+        jobs.append((fx, y))
+    runner.drain()
+    for i, (fx, y) in enumerate(jobs):
+        ref, _, _, _ = cm.forward(fx.data, fx.bits, fx.exp)
+        assert np.array_equal(y.cpu().numpy(), ref), f"batch {i}"

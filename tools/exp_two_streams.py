@@ -11,14 +11,15 @@ from sparsernns_amd.fxpmodel import build_regression_model
 B, L = 32, 4096
 md, qc, dims = synth.make_model(0.5, calib_B=2, calib_L=1024, state_headroom_bits=1)
 engs = []
-for i in range(2):
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+for i in range(NS):
     model = build_regression_model(md, qc, dims["n_layers"])
     eng = model.engine()
     x = synth.make_input(B, L, dims["d_in"], seed=1000 + i)
     fx = fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True, round_mode=RoundingMode.FLOOR)
     y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
     engs.append((eng, fx, y, model))
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+streams = [torch.cuda.Stream() for _ in range(NS)]
 
 def run(n, concurrent):
     torch.cuda.synchronize()
@@ -27,9 +28,9 @@ def run(n, concurrent):
         for i, (eng, fx, y, _) in enumerate(engs):
             s = streams[i] if concurrent else streams[0]
             with torch.cuda.stream(s):
-                eng.enqueue(fx.data, fx.bits, fx.exp, y, B, L)
+                eng.enqueue(fx.data, fx.bits, fx.exp, y, B, L, flags=1)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / (2 * n) * 1e3
+    return (time.perf_counter() - t0) / (NS * n) * 1e3
 
 for c in (False, True, False, True):
     run(3, c)
