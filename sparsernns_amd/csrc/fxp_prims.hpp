@@ -77,11 +77,16 @@ __device__ __forceinline__ int32_t sigmoid_lut(int32_t x, int xbits, int xe, int
 }
 
 // max(0, int(ceil(log2(m + eps)))) in float32 with a correctly rounded log2 (fxparray.py:421-425,
-// 603-607).  Evaluated by one thread per compute_best op, so the double log2 costs nothing.
+// 603-607).  The hardware log2 (v_log_f32, about 1 ulp) decides whenever the result is not within 1e-3 of an
+// integer -- there neither its error nor the rounding of the true log2 to float32 can move the ceiling; only
+// next to an integer the (slow, software) double log2 is evaluated and rounded.  The finalize code that calls
+// this sits at the head and tail of the residual pass, where a few microseconds per workgroup are visible.
 __device__ inline int intbits_f32(float m, float eps)
 {
     const float v = __fadd_rn(m, eps);
-    const float l = (float)log2((double)v);
+    float l = __log2f(v);
+    const float fr = l - floorf(l);
+    if (!(fr > 1e-3f && fr < 1.f - 1e-3f)) l = (float)log2((double)v);
     const int c = (int)ceilf(l);
     return c > 0 ? c : 0;
 }

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *e
 
 // Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
 // layer's BatchNorm operand).  RESID=false: extremes of z only (the encoder output ahead of layer 0).
-// block = 256 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes; four frames in flight
-// per thread.  ext == nullptr: no extremes wanted (last layer).
+// block = 192 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes (16 at H=96, 8 at H=192);
+// a workgroup owns `span` consecutive frames (a multiple of 4R) and keeps four frames per thread in flight.
+// ext == nullptr: no extremes wanted (last layer).
 // Two single-workgroup kernels are folded in (single-rank mode; with a multi-rank hook they stay separate
 // because the ranks exchange maxima in between):
 //   head  the residual add's compute_best exponent (k_res_finalize): every workgroup derives it from the three
@@ -189,16 +190,17 @@ struct ResidTail {
     int32_t enable;
 };
 
+constexpr int RESID_THREADS = 192;
 template <bool RESID>
-__global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
-                                                        int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
-                                                        int res_bits, int skip_bits, ResidHead hd, float *ext, ResidTail tl,
-                                                        int32_t *status)
+__global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
+                                                                  int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
+                                                                  int64_t span, int res_bits, int skip_bits, ResidHead hd,
+                                                                  float *ext, ResidTail tl, int32_t *status)
 {
-    __shared__ int32_t smin[256 * 8], smax[256 * 8];
+    __shared__ int32_t smin[RESID_THREADS * 8], smax[RESID_THREADS * 8];
     __shared__ AddCb sp;
     __shared__ int last;
-    const int G = H >> 3, R = 256 / G;
+    const int G = H >> 3, R = RESID_THREADS / G;
     const int g = threadIdx.x % G, rl = threadIdx.x / G;
     AddCb p{};
     if constexpr (RESID) {
@@ -222,14 +224,15 @@ __global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restric
         lo[e] = 32767;
         hi[e] = -32768;
     }
-    if (rl < R) {
-        const int64_t stride = (int64_t)gridDim.x * R;
-        for (int64_t n0 = (int64_t)blockIdx.x * R + rl; n0 < N; n0 += 4 * stride) {
+    {
+        const int64_t stride = R;
+        const int64_t lo_n = (int64_t)blockIdx.x * span, hi_n = lo_n + span < N ? lo_n + span : N;
+        for (int64_t n0 = lo_n + rl; n0 < hi_n; n0 += 4 * stride) {
             v4i zq[4], sq[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int64_t n = n0 + k * stride;
-                if (n < N) {
+                if (n < hi_n) {
                     zq[k] = *reinterpret_cast<const v4i *>(z + n * H + 8 * g);
                     if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
                 }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void k_resid_minmax16(const int16_t *__restric
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int64_t n = n0 + k * stride;
-                if (n < N) {
+                if (n < hi_n) {
                     int32_t v[8], s[8];
                     unpack8_i16(zq[k], v);
                     if constexpr (RESID) {

@@ -262,7 +262,8 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
 }
 
 template <int KS, int NT, bool TRACE>
-__global__ __launch_bounds__(384, 2) void k_cgate_p(CGateArgs a)
+// <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
+__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
 {
     constexpr int P = 32 * KS, H = 32 * NT, FT = 64, NW = 6;
     constexpr int KPS = 2 * P + 16, KPX = H + 16;

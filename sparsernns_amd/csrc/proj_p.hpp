@@ -214,7 +214,7 @@ __device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], c
 // LDS: [cs128 Np][bias_eff Np][X hi][X lo]
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(384, 2) void k_enc_p(EncArgs a)
+__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
 {
     constexpr int KS = 9, FT = 64, KP = 32 * KS + 16, NW = 6, H = 32 * NT;
     constexpr int NU = 2 * NT / NW, SUBSTEP = NW / NT;
@@ -235,37 +235,44 @@ __global__ __launch_bounds__(384, 2) void k_enc_p(EncArgs a)
         be[i] = a.bias_eff[i];
     }
     const CfgOp cv = make_cfg(a.conv != 0, a.xb, a.xe, a.inp_bits, a.inp_exp);
-    v4i raw[RPW];
-    auto fetch = [&](int64_t tl) {
+    // rows wave, wave+6, ... of the tile; the first RA of them are prefetched across phase B, the rest are
+    // requested at the top of phase A and land while the first are converted (44 registers of prefetch would
+    // push the kernel over the 128 that two workgroups per CU allow)
+    constexpr int RA = 6, RB = RPW - RA;
+    v4i rawa[RA], rawb[RB];
+    auto row_ptr = [&](int64_t tl, int i) {
+        int64_t n = tl * FT + wave + NW * i;
+        n = n < a.N ? n : a.N - 1;
+        return reinterpret_cast<const v4i *>(a.x + n * K + 4 * l); // 4-byte aligned 16-byte load
+    };
+    auto convert_row = [&](const v4i &q, int f, bool &wide) {
+        int32_t v[4];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            int64_t n = tl * FT + wave + NW * i;
-            n = n < a.N ? n : a.N - 1;
-            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * K + 4 * l); // 4-byte aligned 16-byte load
+        for (int e = 0; e < 4; ++e) {
+            v[e] = cv(q[e]);
+            wide |= (v[e] != (int32_t)(int16_t)v[e]);
         }
+        const unsigned p01 = perm((unsigned)v[1], (unsigned)v[0], 0x05010400u), p23 = perm((unsigned)v[3], (unsigned)v[2], 0x05010400u);
+        *reinterpret_cast<int32_t *>(Xl + f * KP + 4 * l) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
+        *reinterpret_cast<int32_t *>(Xh + f * KP + 4 * l) = (int32_t)perm(p23, p01, 0x07060302u);
     };
     int64_t tile = blockIdx.x;
-    if (tile < tiles) fetch(tile);
+    if (tile < tiles) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) rawa[i] = *row_ptr(tile, i);
+    }
     bool wide = false;
     __syncthreads();
     for (; tile < tiles; tile += gridDim.x) {
         const int64_t n0 = tile * FT;
         // ---- phase A
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int f = wave + NW * i;
-            if (f < FT) {
-                int32_t v[4];
+        for (int i = 0; i < RB; ++i) rawb[i] = *row_ptr(tile, RA + i);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = cv(raw[i][e]);
-                    wide |= (v[e] != (int32_t)(int16_t)v[e]);
-                }
-                const unsigned p01 = perm((unsigned)v[1], (unsigned)v[0], 0x05010400u), p23 = perm((unsigned)v[3], (unsigned)v[2], 0x05010400u);
-                *reinterpret_cast<int32_t *>(Xl + f * KP + 4 * l) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
-                *reinterpret_cast<int32_t *>(Xh + f * KP + 4 * l) = (int32_t)perm(p23, p01, 0x07060302u);
-            }
-        }
+        for (int i = 0; i < RA; ++i) convert_row(rawa[i], wave + NW * i, wide);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (wave + NW * (RA + i) < FT) convert_row(rawb[i], wave + NW * (RA + i), wide);
         for (int e = threadIdx.x; e < FT * rem; e += 384) { // the K-256 tail of every row
             const int f = e / rem, k = 256 + e % rem;
             int64_t n = n0 + f;
@@ -275,7 +282,10 @@ __global__ __launch_bounds__(384, 2) void k_enc_p(EncArgs a)
             Xl[f * KP + k] = (int8_t)((v & 0xff) ^ 0x80);
             Xh[f * KP + k] = (int8_t)(v >> 8);
         }
-        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x); // in flight during phase B
+        if (tile + gridDim.x < tiles) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) rawa[i] = *row_ptr(tile + gridDim.x, i); // in flight during phase B
+        }
         __syncthreads();
         // ---- phase B
 #pragma unroll

@@ -256,6 +256,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     };
     auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid6, smem, args); };
 
+    // residual / extremes pass: a workgroup owns rm_span consecutive frames, a multiple of its 4 x R frame step
+    const int64_t rm_step = 4 * (RESID_THREADS / (H / 8)), rm_iters = (N + rm_step - 1) / rm_step;
+    const int64_t rm_per = (rm_iters + 511) / 512, rm_span = rm_per * rm_step;
+    const unsigned rm_grid = (unsigned)((rm_iters + rm_per - 1) / rm_per);
+
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
     // ---- encoder + ReLU
     {
@@ -325,8 +330,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 ResidTail tl{};
                 tl.bn = bn; tl.d_next = d; tl.status_exps_next = st_exps; tl.ticket = &d->pad1[0];
                 tl.xe_static = m->enc.out_exp; tl.enable = fold ? 1 : 0;
-                hipLaunchKernelGGL(k_resid_minmax16<false>, dim3(512), dim3(256), 0, st, (const int16_t *)h,
-                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, 0, 0, ResidHead{},
+                hipLaunchKernelGGL(k_resid_minmax16<false>, dim3(rm_grid), dim3(RESID_THREADS), 0, st, (const int16_t *)h,
+                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, rm_span, 0, 0, ResidHead{},
                                    ext, tl, status);
             }
             if (!fold) {
@@ -506,8 +511,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 tl.bn = make_bn(li + 1, l.res_bits, DynExp{0, &d->res.eo});
                 tl.d_next = d + 1; tl.status_exps_next = st_exps + 8; tl.ticket = &(d + 1)->pad1[0]; tl.enable = 1;
             }
-            hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(512), dim3(256), 0, st, (const int16_t *)I16(w.z),
-                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, l.res_bits, hb, hd, ext_next, tl, status);
+            hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(rm_grid), dim3(RESID_THREADS), 0, st, (const int16_t *)I16(w.z),
+                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, rm_span, l.res_bits, hb, hd, ext_next, tl,
+                               status);
         } else {
             hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z),
                                (const int16_t *)h, hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
