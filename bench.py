@@ -52,7 +52,8 @@ def main() -> None:
     ap.add_argument("--quantization", default="w8a16")
     ap.add_argument("--state-headroom-bits", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="sequences in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="sequences per pass of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
     ap.add_argument("--inflight", type=int, default=3, help="batches in flight (streams); 1 = one forward at a time")
     ap.add_argument("--self-contained", action="store_true",
@@ -170,7 +171,7 @@ def main() -> None:
     st0 = check_all(depth)
 
     # ---- the same K steps one at a time (no overlap between batches), for reference; not the headline
-    single = None
+    single, ev1 = None, None
     if depth > 1:
         ev1 = make_events(args.steps)
         torch.cuda.synchronize()
@@ -189,13 +190,21 @@ def main() -> None:
     frames = B * L * world * args.steps
     value = frames / dt
 
-    # ---- roofline of the dominant kernel (the recurrence): algorithmic bytes = 16*P per frame per layer
-    scan_avg_s = scan_avg(events)
+    # ---- roofline of the recurrence kernel: algorithmic bytes = 16*P per frame per layer.  Its launch duration is
+    # taken where the kernel has the GPU to itself (the one-at-a-time pass of the same K steps when batches are in
+    # flight: there its launches share the chip with other batches' projections and the bracket measures the
+    # sharing, not the kernel -- that figure is reported beside it).
+    scan_inflight_s = scan_avg(events)
+    scan_avg_s = scan_avg(ev1) if depth > 1 else scan_inflight_s
     algo_bytes = B * L * dims["P"] * 16
     achieved = algo_bytes / scan_avg_s / 1e9
-    roofline = dict(bound="hbm", kernel="scan", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(B, L, dims["P"]),
-                    avg_kernel_us=round(scan_avg_s * 1e6, 2), algorithmic_bytes_per_launch=algo_bytes)
+    roofline = dict(bound="hbm", kernel="k_scan_quad_asm (the S5 recurrence)", achieved=round(achieved, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                    traffic=pmc_traffic(B, L, dims["P"]), avg_kernel_us=round(scan_avg_s * 1e6, 2),
+                    algorithmic_bytes_per_launch=algo_bytes,
+                    measured=("HIP events around every launch, one layer per step, " +
+                              ("in the one-at-a-time pass of the same K steps" if depth > 1 else "in the timed region")),
+                    avg_kernel_us_sharing_the_gpu=round(scan_inflight_s * 1e6, 2) if depth > 1 else None)
 
     # ---- RCCL output gather, exercised once outside the timed region
     gather_ms = None
@@ -215,13 +224,18 @@ def main() -> None:
         cb = min(args.cpu_batch, B)
         cm = cref.CModel(model.export())
         xs_host = fx.data[:cb].cpu().numpy()
-        c0 = time.perf_counter()
-        ref, _, _, _ = cm.forward(xs_host, fx.bits, fx.exp)
-        cdt = time.perf_counter() - c0
-        same = bool(np.array_equal(ref, y[:cb].cpu().numpy())) if cb == B else None
-        cpu = dict(value=round(cb * L / cdt, 1), unit="frames/s", cores=cref.num_threads(), kind="port",
-                   sample=f"{cb} sequences x {L} frames of the same workload, one pass, OpenMP scalar C restatement "
-                          f"(oracle/s5fxp_ref.c); the reference's JAX path is not installable offline",
+        passes, c0 = 0, time.perf_counter()
+        while True:  # whole passes over the same cb sequences until ~cpu_seconds have gone (at least one)
+            ref, _, _, _ = cm.forward(xs_host, fx.bits, fx.exp)
+            passes += 1
+            cdt = time.perf_counter() - c0
+            if cdt >= args.cpu_seconds or passes >= 64:
+                break
+        same = bool(np.array_equal(ref, y[:cb].cpu().numpy()))
+        cpu = dict(value=round(passes * cb * L / cdt, 1), unit="frames/s", cores=cref.num_threads(), kind="port",
+                   sample=f"{passes} passes over {cb} sequences x {L} frames of the same workload (lane 0's batch), "
+                          f"OpenMP scalar C restatement (oracle/s5fxp_ref.c); the reference's JAX path is not "
+                          f"installable offline",
                    seconds=round(cdt, 2), matches_gpu=same)
 
     if rank == 0:

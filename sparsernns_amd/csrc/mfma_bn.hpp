@@ -9,9 +9,9 @@
 //     over the tensor (k_resid_minmax16, fused with the previous layer's residual add) and one single-workgroup kernel (k_bn_finalize_mm) replace four reduction
 //     passes.  The results are identical by construction; tests compare against the oracle's full reductions.
 //
-// (2) k_bproj_mfma2: same arithmetic as k_bproj_mfma, but BatchNorm parameters come from LDS, the chain runs
-//     four elements at a time (bounded live registers), traces are compiled out unless requested, and the
-//     SSM input u is written once (int16) so the C projection does not recompute the chain.
+// (2) the lean 16-bit BatchNorm chain (Bn16) and the argument block of the B projection (kernel: proj_p.hpp
+//     k_bproj_p): BatchNorm parameters come from LDS, the chain runs four elements at a time, and the SSM input u
+//     is written once (int16) so the C projection does not recompute the chain.
 #pragma once
 #include "mfma_proj.hpp"
 
@@ -352,7 +352,7 @@ __device__ __forceinline__ void bn16_x4(const Bn16 &p, const int32_t (&x)[4], in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lean B projection.  LDS: [weights][cs128 Np][m1 H][isv H][scale H][bias H]
+// B projection arguments (kernel: proj_p.hpp k_bproj_p)
 // ---------------------------------------------------------------------------------------------
 struct BprojM2Args {
     BnArgs bn;
@@ -366,96 +366,5 @@ struct BprojM2Args {
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
     int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
 };
-
-template <int KS, int NT, bool TRACE>
-__global__ __launch_bounds__(256, 2) void k_bproj_mfma2(BprojM2Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-    const int wbytes = a.w.Np * a.w.Kp, H = a.H;
-    int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes);
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + 31) / 32;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    // this wave's first fragments are requested before the weights: one round of memory latency, not two
-    v4i raw[KS][2];
-    auto fetch = [&](int64_t tl) {
-        int64_t n = tl * 32 + r;
-        n = n < a.N ? n : a.N - 1;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            raw[ks][0] = *reinterpret_cast<const v4i *>(a.x + n * H + 32 * ks + 16 * h);
-            raw[ks][1] = *reinterpret_cast<const v4i *>(a.x + n * H + 32 * ks + 16 * h + 8);
-        }
-    };
-    if (tile < tiles) fetch(tile);
-    const LayerDyn d = *a.bn.dyn;
-    stage_lds(smem, a.w.wt, wbytes);
-    stage_lds(cs, a.w.cs128, a.w.Np * 4);
-    const Bn16 bn = bn16_setup(a.bn, d, cs + a.w.Np, H);
-    __syncthreads();
-    const unsigned blk_words = (unsigned)a.P * 8u;
-    for (; tile < tiles; tile += stride) {
-        const int64_t n = tile * 32 + r;
-        v4i hi[KS], lo[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k0 = 32 * ks + 16 * h;
-            int32_t v[16];
-            unpack_i16(raw[ks][0], raw[ks][1], v);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int32_t xin[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, t[4], u[4];
-                bn16_x4(bn, xin, k0 + 4 * q, t, u);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (TRACE) {
-                        if (a.tr_pre_s5 && n < a.N) a.tr_pre_s5[n * H + k0 + 4 * q + e] = t[e];
-                        if (a.tr_u && n < a.N) a.tr_u[n * H + k0 + 4 * q + e] = u[e];
-                    }
-                    v[4 * q + e] = u[e];
-                }
-                if (n < a.N) *reinterpret_cast<v2i *>(a.u + n * H + k0 + 4 * q) = pack4_i16(u[0], u[1], u[2], u[3]);
-                S5_FENCE();
-            }
-            planes_from_i32(v, hi[ks], lo[ks]);
-            S5_FENCE();
-        }
-        if (tile + stride < tiles) fetch(tile + stride); // next tile's fragments fly during the MFMAs and the epilogue
-        v16i acc[NT];
-        mfma_2plane<KS, NT>(acc, smem, a.w.Kp, cs, 0, hi, lo);
-        S5_FENCE();
-        if (n < a.N) {
-            const int64_t b = n / a.L;
-            const int t = (int)(n - b * a.L);
-            // 2P = 32*NT channels, so P is a compile-time constant here and every store below is one per-lane
-            // base (frame, lane half) plus an immediate offset -- no per-element address arithmetic
-            constexpr int PC = 16 * NT;
-            int32_t *dst = a.bq + ((b * a.TB + (t >> 2)) * (int64_t)blk_words + (t & 3)) + 32 * h; // + (p*2 + c)*4, p = .. + 4h
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int c = (32 * ct >= PC) ? 1 : 0;
-                const int rs = c ? a.rs_im : a.rs_re, bits = c ? a.bim_bits : a.bre_bits, sh = c ? a.sh_im : a.sh_re;
-                const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int p0 = 32 * ct + 8 * g - c * PC; // + 4h is in dst
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int32_t bu = sat(asr(acc[ct][4 * g + e], rs), bits);
-                        dst[((p0 + e) * 2 + c) * 4] = asr(wshl(bu, lsh), rsh);
-                        if (TRACE) {
-                            if (!c && a.tr_bu_re) a.tr_bu_re[n * PC + p0 + 4 * h + e] = bu;
-                            if (c && a.tr_bu_im) a.tr_bu_im[n * PC + p0 + 4 * h + e] = bu;
-                        }
-                    }
-                }
-                S5_FENCE();
-            }
-        }
-    }
-}
 
 } // namespace s5

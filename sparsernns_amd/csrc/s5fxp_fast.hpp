@@ -11,7 +11,6 @@ struct MfmaWDev {
 
 struct FastLayer {
     MfmaWDev bproj, cre, cim, out2;
-    MfmaWDev out2p; // out2 with the k-order of every 32-block permuted to the accumulator layout (mfma_fused.hpp)
     const int32_t *Dpad = nullptr; // [Np]
 };
 
@@ -103,10 +102,8 @@ bool fast_eligible(const s5fxp_model_desc *d)
 }
 
 // get(k, ch) -> weight; result rows are channels, padded and strided for conflict-free 16-byte LDS reads
-// kperm: within each block of 32 k, position 16*h + 4*g + e holds the weight of k = 8*g + 4*h + e, the order
-// in which a lane of the previous MFMA's accumulator tile holds its channels
 template <class Get>
-void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o, bool kperm = false)
+void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o)
 {
     const int Kpad = (K + 31) / 32 * 32;
     const int Kp = ((Kpad / 16) % 2 == 0) ? Kpad + 16 : Kpad;
@@ -117,12 +114,7 @@ void pack_mfma(Packer &p, Get get, int K, int M, MfmaWDev &o, bool kperm = false
         uint32_t sum = 0;
         for (int k = 0; k < K; ++k) {
             const int32_t v = get(k, ch);
-            int pos = k;
-            if (kperm) {
-                const int blk = k & ~31, kk = k & 31, g = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3;
-                pos = blk + 16 * hh + 4 * g + e;
-            }
-            wt[(size_t)ch * Kp + pos] = (int8_t)v;
+            wt[(size_t)ch * Kp + k] = (int8_t)v;
             sum += (uint32_t)v;
         }
         cs[ch] = (int32_t)(sum * 128u);
@@ -159,7 +151,6 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
         pack_mfma(p, [&](int k, int ch) { return s.C_im[(size_t)ch * P + k]; }, P, H, o.cim);
         pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2);
         pack_bias_eff(p, l.out2, o.out2.w.Np, o.out2);
-        pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2p, true);
         std::vector<int32_t> Dp(o.cre.w.Np, 0);
         for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
         o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
