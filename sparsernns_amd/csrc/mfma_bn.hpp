@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *e
 
 // Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
 // layer's BatchNorm operand).  RESID=false: extremes of z only (the encoder output ahead of layer 0).
-// block = 192 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes (16 at H=96, 8 at H=192);
+// block = 384 threads = G8 channel-groups (8 channels = 16 bytes each) x R frame lanes (32 at H=96, 16 at H=192);
 // a workgroup owns `span` consecutive frames (a multiple of 4R) and keeps four frames per thread in flight.
 // ext == nullptr: no extremes wanted (last layer).
 // Two single-workgroup kernels are folded in (single-rank mode; with a multi-rank hook they stay separate
@@ -190,7 +190,7 @@ struct ResidTail {
     int32_t enable;
 };
 
-constexpr int RESID_THREADS = 192;
+constexpr int RESID_THREADS = 384;
 template <bool RESID>
 __global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
                                                                   int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,

@@ -171,6 +171,8 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
 }
 
 // uniform operands of a change_cfg (fxp_prims.hpp chcfg) applied to many elements; `on` false = identity
+using v2u16 = __attribute__((ext_vector_type(2))) unsigned short;
+
 struct CfgOp {
     int l, r, b;
     __device__ __forceinline__ int32_t operator()(int32_t d) const { return sat(asr(wshl(d, l), r), b); }
@@ -211,10 +213,13 @@ __device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], c
 // Encoder, phase-split: x int32 (N,K) -> relu(dense) int16 (N,H).  fxpmodel.py:331-366, 1263-1266.
 // Six waves, 64-frame tiles.  Phase A: a wave reads whole rows (64 lanes x 4 consecutive k, 1 KB contiguous)
 // plus the K-256 tail, converts, and writes byte planes [frame][304]; phase B: wave (half, column tile).
-// LDS: [cs128 Np][bias_eff Np][X hi][X lo]
+// ext != nullptr: the per-channel extremes of the output (layer 0's BatchNorm operand, mfma_bn.hpp) are gathered
+// on the way -- a lane keeps (max, 65535 - min) of its 16 channels as packed u16 pairs (the output is >= 0 after
+// the ReLU) -- and with tl.enable the workgroup that finishes last derives layer 0's BatchNorm exponents.
+// LDS: [cs128 Np][bias_eff Np][X hi][X lo][ext hi H][ext lo H]
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
+__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float *ext, ResidTail tl)
 {
     constexpr int KS = 9, FT = 64, KP = 32 * KS + 16, NW = 6, H = 32 * NT;
     constexpr int NU = 2 * NT / NW, SUBSTEP = NW / NT;
@@ -222,10 +227,14 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *cs = reinterpret_cast<int32_t *>(smem), *be = cs + H;
     int8_t *Xh = reinterpret_cast<int8_t *>(be + H), *Xl = Xh + FT * KP;
+    uint32_t *ehi = reinterpret_cast<uint32_t *>(Xl + FT * KP), *elo = ehi + H;
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT, ch0 = 32 * ct + 4 * h;
     const int64_t tiles = (a.N + FT - 1) / FT;
     const int K = a.K, rem = K - 256;
+    uint32_t pk[16]; // low half: max, high half: 65535 - min
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pk[i] = 0;
     v4i wreg[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -233,12 +242,14 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
     for (int i = threadIdx.x; i < H; i += 384) {
         cs[i] = a.w.cs128[i];
         be[i] = a.bias_eff[i];
+        ehi[i] = 0;
+        elo[i] = 0;
     }
     const CfgOp cv = make_cfg(a.conv != 0, a.xb, a.xe, a.inp_bits, a.inp_exp);
     // rows wave, wave+6, ... of the tile; the first RA of them are prefetched across phase B, the rest are
     // requested at the top of phase A and land while the first are converted (44 registers of prefetch would
     // push the kernel over the 128 that two workgroups per CU allow)
-    constexpr int RA = 6, RB = RPW - RA;
+    constexpr int RA = 3, RB = RPW - RA;
     v4i rawa[RA], rawb[RB];
     auto row_ptr = [&](int64_t tl, int i) {
         int64_t n = tl * FT + wave + NW * i;
@@ -306,6 +317,10 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
                             int32_t v = sat(asr(acc[4 * g + e], a.rs), a.out_bits);
                             v = sat(wadd(v, bv[e]), a.out_bits);
                             o[e] = v < 0 ? 0 : v;
+                            // (v, 65535 - v) as a u16 pair; one packed max keeps both running extremes
+                            const uint32_t t = (uint32_t)__umul24((unsigned)o[e], 0x10001u) ^ 0xffff0000u;
+                            pk[4 * g + e] = __builtin_bit_cast(
+                                uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, pk[4 * g + e]), __builtin_bit_cast(v2u16, t)));
                         }
                         *reinterpret_cast<v2i *>(a.y + n * a.M + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
                     }
@@ -315,6 +330,38 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a)
         __syncthreads(); // planes are single-buffered
     }
     if (__any(wide) && l == 0) atomicOr(a.status, ST_WIDE_INPUT);
+    if (!ext) return;
+    // ---- extremes: fold the 32 frame lanes of each half wave, then the waves of the workgroup (LDS), then one
+    // atomic per channel and bound
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t v = pk[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+            const uint32_t lo16 = (v & 0xffffu) > (w & 0xffffu) ? (v & 0xffffu) : (w & 0xffffu);
+            const uint32_t hi16 = (v >> 16) > (w >> 16) ? (v >> 16) : (w >> 16);
+            v = lo16 | (hi16 << 16);
+        }
+        const int ch = ch0 + 8 * (i >> 2) + (i & 3);
+        if (r == 0 && ch < a.M) {
+            atomicMax(&ehi[ch], v & 0xffffu);
+            atomicMax(&elo[ch], v >> 16);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.M) { // max = ehi, min = 65535 - elo; as the positive floats of mfma_bn.hpp
+        const int c = threadIdx.x;
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)(65535 - (int)elo[c])));
+        atomicMax(reinterpret_cast<uint32_t *>(ext) + a.M + c, __float_as_uint(EXT_BIAS + (float)ehi[c]));
+    }
+    if (!tl.enable) return;
+    __shared__ int last;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last) bn_finalize_mm_body(tl.bn, ext, a.M, tl.d_next, a.status, tl.status_exps_next, tl.xe_static);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -246,6 +246,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         hipLaunchKernelGGL(kernel, dim3(g6), dim3(384), smem, st, args);
     };
     auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid6, smem, args); };
+    auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, const ResidTail &tl) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kernel, dim3(grid6), dim3(384), smem, st, args, ext, tl);
+    };
 
     // residual / extremes pass: a workgroup owns rm_span consecutive frames, a multiple of its 4 x R frame step
     const int64_t rm_step = 4 * (RESID_THREADS / (H / 8)), rm_iters = (N + rm_step - 1) / rm_step;
@@ -253,20 +258,6 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const unsigned rm_grid = (unsigned)((rm_iters + rm_per - 1) / rm_per);
 
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
-    // ---- encoder + ReLU
-    {
-        const DenseDev &e = m->enc;
-        EncArgs a{};
-        a.x = x; a.y = h; a.w = F.enc.w; a.bias_eff = F.enc.bias_eff; a.N = N; a.K = e.K; a.M = e.M;
-        a.xb = x_bits; a.xe = x_exp; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp;
-        a.conv = (x_bits > e.inp_bits || x_exp > e.inp_exp) ? 1 : 0;
-        a.rs = (a.conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp;
-        if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
-        a.out_bits = e.out_bits; a.status = status;
-        const size_t smem = 2 * (size_t)H * 4 + 2 * 64 * 304; // cs128 + bias_eff + byte planes
-        if (big) launch6(k_enc_p<6>, smem, a);
-        else launch6(k_enc_p<3>, smem, a);
-    }
     int hb = m->enc.out_bits;
     DynExp he{m->enc.out_exp, nullptr};
     // BatchNorm arguments of layer li, whose input has hb_in bits and the (device) exponent he_in
@@ -284,6 +275,29 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         bn.ub = s.u_bits; bn.ue = s.u_exp; bn.out_bits = bn.b4; bn.dyn = dyn + li;
         return bn;
     };
+    // ---- encoder + ReLU
+    {
+        const DenseDev &e = m->enc;
+        EncArgs a{};
+        a.x = x; a.y = h; a.w = F.enc.w; a.bias_eff = F.enc.bias_eff; a.N = N; a.K = e.K; a.M = e.M;
+        a.xb = x_bits; a.xe = x_exp; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp;
+        a.conv = (x_bits > e.inp_bits || x_exp > e.inp_exp) ? 1 : 0;
+        a.rs = (a.conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp;
+        if (!shift_ok(a.rs)) return S5FXP_ENEGSHIFT;
+        a.out_bits = e.out_bits; a.status = status;
+        const size_t smem = 4 * (size_t)H * 4 + 2 * 64 * 304; // cs128 + bias_eff + byte planes + extremes
+        // the extremes of the output (layer 0's BatchNorm operand) are gathered on the way; single-rank mode also
+        // lets the last workgroup derive layer 0's BatchNorm exponents (mfma_bn.hpp ResidTail)
+        float *ext0 = bn_ext && m->n_layers > 0 ? reinterpret_cast<float *>(ws + w.ext) : nullptr;
+        ResidTail tl{};
+        if (ext0 && bn_ext && !allreduce) {
+            tl.bn = make_bn(0, m->enc.out_bits, DynExp{m->enc.out_exp, nullptr});
+            tl.d_next = dyn; tl.status_exps_next = status + 8; tl.ticket = &dyn->pad1[0];
+            tl.xe_static = m->enc.out_exp; tl.enable = 1;
+        }
+        if (big) launch6x(k_enc_p<6>, smem, a, ext0, tl);
+        else launch6x(k_enc_p<3>, smem, a, ext0, tl);
+    }
     // step chunks of the bproj | scan | cgate pipeline (see Pipeline): multiples of 64 steps, the last takes the rest
     int n_chunks = 1, c_lo[MAX_CHUNKS + 1] = {0, L};
     if (!exact && !traces && !allreduce) {
@@ -317,14 +331,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (bn_ext) {
             float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H;
             // layer 0: extremes of the encoder output; later layers: the previous layer's residual pass left them
-            if (li == 0) {
-                ResidTail tl{};
-                tl.bn = bn; tl.d_next = d; tl.status_exps_next = st_exps; tl.ticket = &d->pad1[0];
-                tl.xe_static = m->enc.out_exp; tl.enable = fold ? 1 : 0;
-                hipLaunchKernelGGL(k_resid_minmax16<false>, dim3(rm_grid), dim3(RESID_THREADS), 0, st, (const int16_t *)h,
-                                   (const int16_t *)nullptr, (int16_t *)nullptr, (int32_t *)nullptr, N, H, rm_span, 0, 0, ResidHead{},
-                                   ext, tl, status);
-            }
+            // layer 0: the encoder left the extremes; later layers: the previous layer's residual pass
             if (!fold) {
                 // mode A: the extremes (positive floats) are what the ranks exchange -- one MAX over 2H values
                 if (allreduce && allreduce(allreduce_ctx, ext, 2 * H, (void *)st)) return S5FXP_EHIP;
