@@ -323,3 +323,16 @@ def test_two_rank_protocol_over_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"RANK{r} modeA=True modeB=True" in o, o
+
+
+def test_fxprun_cli_fails_loudly_without_gpu_and_reads_the_interchange_format():
+    import torch
+    from sparsernns_amd import fxprun
+
+    if not torch.cuda.is_available():
+        assert fxprun.main(["--synthetic", "--steps", "0"]) == 2  # no CPU fallback
+    md, meta, export, x, y, inter = load_golden("tiny_a")
+    ex2, meta2 = fxprun.load_export(os.path.join(GOLD, "tiny_a.npz"), os.path.join(GOLD, "tiny_a.json"))
+    assert ex2["qconfig"] == export["qconfig"]
+    a, b = fxprun._flatten(ex2["params"]), fxprun._flatten(export["params"])
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)

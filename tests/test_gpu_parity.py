@@ -371,3 +371,35 @@ def test_inflight_runner_matches_oracle_per_batch():
     for i, (fx, y) in enumerate(jobs):
         ref, _, _, _ = cm.forward(fx.data, fx.bits, fx.exp)
         assert np.array_equal(y.cpu().numpy(), ref), f"batch {i}"
+
+
+def test_fxprun_cli_validate_verify_export_reload(tmp_path):
+    """The command line end to end: synthetic model, verification (op-by-op == fused), export, reload of the
+    exported integer model, same outputs."""
+    from sparsernns_amd import fxprun
+
+    pre, o1, o2 = str(tmp_path / "m"), str(tmp_path / "y1.npy"), str(tmp_path / "y2.npy")
+    common = ["--seq_len", "128", "--bsz", "2", "--seed", "5"]
+    assert fxprun.main(["--synthetic", "--verify", "--export", pre, "--outputs", o1, "--steps", "3", "--inflight", "2"] + common) == 0
+    assert fxprun.main(["--model", pre + ".npz", "--meta", pre + ".json", "--outputs", o2, "--steps", "1"] + common) == 0
+    assert np.array_equal(np.load(o1), np.load(o2))
+
+
+def test_step_chunk_pipeline_knob_is_exact():
+    """S5FXP_CHUNKS=2: bproj | scan | cgate in two step chunks with the recurrence on a side stream (the scan
+    kernel starts its second chunk from the stored last state of the first).  Off by default (slower), but the
+    step-range arguments and the initial-state input must stay right."""
+    import os
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    fx = _input(qc, dims, 2, 576, seed=21)  # chunks [0,256) and [256,576): the second one is ragged
+    os.environ["S5FXP_CHUNKS"] = "2"
+    try:
+        model = build_regression_model(md, qc, dims["n_layers"])
+        y = model.engine().forward(FxpArray(fx.data, fx.bits, fx.exp))
+    finally:
+        del os.environ["S5FXP_CHUNKS"]
+    ref, _, _, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
+    assert np.array_equal(y.numpy(), ref)
