@@ -32,6 +32,7 @@ struct CGateArgs {
     int32_t *status;
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
     int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
+    const int32_t *sigtab; // [2][7 << sig_x]: gate operand r for a non-positive / positive sigmoid input (k_cgate_p)
 };
 
 // multi-rank mode only: the residual maxima of a re-run layer live in slots 11..13; move them to 8..10, the
@@ -75,6 +76,8 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
     }
 }
 
+constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checked)
+
 template <int KS, int NT, bool TRACE>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
     constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + 383) / 384;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
-    int8_t *Sh = reinterpret_cast<int8_t *>(lutp + 8), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
+    int32_t *sigt = lutp + 8; // SIGTAB_WORDS
+    int8_t *Sh = reinterpret_cast<int8_t *>(sigt + SIGTAB_WORDS), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
         csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i]; be[i] = a.bias_eff[i];
     }
     if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
+    for (int i = threadIdx.x; i < (14 << a.sig_x); i += 384) sigt[i] = a.sigtab[i];
     const int skip_e = a.skip_e.get();
     const float kz = ldexpf(1.f, skip_e - a.res_exp); // fz + fs = 2^-skip_e * (z * kz + s), exactly
     const int sx = a.sig_x, S = 1 << sx;
@@ -199,7 +204,11 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
                     }
                     const int32_t x1 = y < 0 ? 0 : y;
                     x1v[u][4 * g + e] = x1;
-                    xv[e] = sat(asr(wshl(x1, cv_l), cv_r), cv_b);
+                    xv[e] = x1;
+                }
+                if (a.conv) { // uniform: the out2 input conversion is usually the identity
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e] = sat(asr(wshl(xv[e], cv_l), cv_r), cv_b);
                 }
                 const unsigned p01 = perm((unsigned)xv[1], (unsigned)xv[0], 0x05010400u), p23 = perm((unsigned)xv[3], (unsigned)xv[2], 0x05010400u);
                 const int off = (32 * sub + r) * KPX + ch0 + 8 * g;
@@ -226,17 +235,25 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
                     for (int e = 0; e < 4; ++e) {
                         int32_t gq = sat(asr(acc[4 * g + e], a.rs_o2), a.out_bits);
                         gq = sat(gq + bv[e], a.out_bits);
-                        // LUT sigmoid (fxp_prims.hpp sigmoid_lut) with the two table entries in one LDS word
+                        // LUT sigmoid (fxp_prims.hpp sigmoid_lut) + change_cfg to the gate's r operand.  Both are
+                        // functions of the sign of xx and of (min(|xx| >> sx, 6), |xx| mod 2^sx) only: 2 x 7 x 2^sx
+                        // values, tabulated by the host with the same formula (s5fxp_fast.hpp).  The TRACE
+                        // instantiation computes s the long way (it has to write it out).
                         const int32_t xx = chexp(gq, a.out_bits, a.out_exp, sx);
                         const int32_t ax = xx < 0 ? -xx : xx;
                         int32_t ind = ax >> sx;
                         ind = ind > 6 ? 6 : ind;
                         const int32_t mu = ax & (S - 1);
-                        const uint32_t pr = (uint32_t)lutp[ind];
-                        const int32_t half = (__mul24(S - mu, (int32_t)(pr & 0xffffu)) >> sx) + (__mul24(mu, (int32_t)(pr >> 16)) >> sx);
-                        const int32_t s = (1 << (a.sig_y - 1)) + (xx > 0 ? half : -half);
+                        int32_t s = 0, rq;
+                        if (TRACE) {
+                            const uint32_t pr = (uint32_t)lutp[ind];
+                            const int32_t half = (__mul24(S - mu, (int32_t)(pr & 0xffffu)) >> sx) + (__mul24(mu, (int32_t)(pr >> 16)) >> sx);
+                            s = (1 << (a.sig_y - 1)) + (xx > 0 ? half : -half);
+                            rq = chcfg(s, a.out_bits, a.sig_y, a.r_bits, a.r_exp);
+                        } else {
+                            rq = sigt[((ind << sx) | mu) + (xx > 0 ? 7 * S : 0)];
+                        }
                         const int32_t lq = chcfg(x1v[u][4 * g + e], a.y_bits, a.y_exp, a.l_bits, a.l_exp);
-                        const int32_t rq = chcfg(s, a.out_bits, a.sig_y, a.r_bits, a.r_exp);
                         const int32_t z = sat(asr(__mul24(lq, rq), a.rs_gate), a.res_bits);
                         if (TRACE) {
                             if (a.tr_out2) a.tr_out2[n * H + ch + e] = gq;

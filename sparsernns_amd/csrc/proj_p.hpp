@@ -257,12 +257,13 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
         return reinterpret_cast<const v4i *>(a.x + n * K + 4 * l); // 4-byte aligned 16-byte load
     };
     auto convert_row = [&](const v4i &q, int f, bool &wide) {
-        int32_t v[4];
+        int32_t v[4] = {q[0], q[1], q[2], q[3]};
+        if (a.conv) { // uniform: usually the input already has the encoder's configuration
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = cv(q[e]);
-            wide |= (v[e] != (int32_t)(int16_t)v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = cv(v[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wide |= (v[e] != (int32_t)(int16_t)v[e]);
         const unsigned p01 = perm((unsigned)v[1], (unsigned)v[0], 0x05010400u), p23 = perm((unsigned)v[3], (unsigned)v[2], 0x05010400u);
         *reinterpret_cast<int32_t *>(Xl + f * KP + 4 * l) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
         *reinterpret_cast<int32_t *>(Xh + f * KP + 4 * l) = (int32_t)perm(p23, p01, 0x07060302u);

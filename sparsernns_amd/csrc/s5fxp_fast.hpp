@@ -12,6 +12,7 @@ struct MfmaWDev {
 struct FastLayer {
     MfmaWDev bproj, cre, cim, out2;
     const int32_t *Dpad = nullptr; // [Np]
+    const int32_t *sigtab = nullptr; // [2][7 << sig_x] (mfma_fused.hpp k_cgate_p)
 };
 
 // The recurrence keeps only B*P/16 waves busy for ~50 us per layer while the projections on either side of it
@@ -97,6 +98,7 @@ bool fast_eligible(const s5fxp_model_desc *d)
             return false;
         for (int i8 = 0; i8 < 8; ++i8) // the fused gate kernel keeps two LUT entries per 32-bit word
             if (l.lut[i8] < 0 || l.lut[i8] > 65535) return false;
+        if (l.sig_x_exp > 6) return false; // the reference's rule is min(out2.out_exp, 6) (fxpmodel.py:1097-1104); the r table assumes it
     }
     return true;
 }
@@ -154,6 +156,18 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
         std::vector<int32_t> Dp(o.cre.w.Np, 0);
         for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
         o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
+        // gate operand r = change_cfg(sigmoid(xx)) for every (sign, min(|xx| >> sx, 6), |xx| mod 2^sx): fxpmodel.py:97-144
+        // + :1075-1093, the same integer formula as fxp_prims.hpp sigmoid_lut
+        const int sx = l.sig_x_exp, S = 1 << sx, sy = l.sig_y_exp;
+        std::vector<int32_t> tab((size_t)14 * S);
+        for (int pos = 0; pos < 2; ++pos)
+            for (int i = 0; i < 7 * S; ++i) {
+                const int ind = i >> sx, mu = i & (S - 1);
+                const int32_t half = wadd(asr(wmul(S - mu, l.lut[ind]), sx), asr(wmul(mu, l.lut[ind + 1]), sx));
+                const int32_t sg = wadd(1 << (sy - 1), pos ? half : wsub(0, half));
+                tab[(size_t)pos * 7 * S + i] = chcfg(sg, l.out2.out_bits, sy, l.r_bits, l.r_exp);
+            }
+        o.sigtab = reinterpret_cast<const int32_t *>(put_raw(p, tab.data(), tab.size() * 4));
     }
     const s5fxp_dense_desc &dd = d->decoder;
     pack_mfma(p, [&](int k, int ch) { return dd.weight[(size_t)k * dd.M + ch]; }, dd.K, dd.M, f->dec);
@@ -433,7 +447,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         {
             CGateArgs a{};
             a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2.w;
-            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z);
+            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab;
             a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H;
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
@@ -446,7 +460,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
-            const size_t smem = 5 * (size_t)H * 4 + 32 + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
+            const size_t smem = 5 * (size_t)H * 4 + 32 + 4 * SIGTAB_WORDS + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
