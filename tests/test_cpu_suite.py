@@ -336,3 +336,30 @@ def test_fxprun_cli_fails_loudly_without_gpu_and_reads_the_interchange_format():
     assert ex2["qconfig"] == export["qconfig"]
     a, b = fxprun._flatten(ex2["params"]), fxprun._flatten(export["params"])
     assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_audio_front_and_back_end_match_scipy():
+    """STFT / iSTFT / SI-SNR of the denoising loop (train_helpers.py:15-53,1382-1412) against scipy.signal, which
+    jax.scipy.signal mirrors; lengths that are and are not a multiple of the hop."""
+    import scipy.signal
+    import torch
+    from sparsernns_amd import audio
+
+    rng = np.random.default_rng(3)
+    for T in (4096, 5000, 777):
+        x = rng.standard_normal((2, T)).astype(np.float32)
+        _, _, Z = scipy.signal.stft(x, nperseg=512, nfft=512, noverlap=384, window="boxcar", return_onesided=True)
+        mag, ph = audio.stft_splitter(torch.from_numpy(x))
+        assert tuple(mag.shape) == Z.shape
+        z = torch.polar(mag, ph).numpy()
+        assert np.allclose(z, Z, atol=2e-6), np.abs(z - Z).max()
+        _, xr = scipy.signal.istft(Z, nperseg=512, nfft=512, noverlap=384, window="boxcar", input_onesided=True)
+        back = audio.stft_mixer(mag, ph).numpy()
+        assert back.shape == xr.shape and np.allclose(back, xr, atol=2e-5), np.abs(back - xr).max()
+        assert np.allclose(back[:, :T], x, atol=2e-5)
+    t = rng.standard_normal((3, 2000)).astype(np.float32)
+    e = (t + 0.1 * rng.standard_normal((3, 2000))).astype(np.float32)
+    st, se = t - t.mean(-1, keepdims=True), e - e.mean(-1, keepdims=True)
+    proj = (st * se).sum(-1, keepdims=True) * st / (st ** 2).sum(-1, keepdims=True)
+    want = 10 * np.log10((proj ** 2).sum(-1) / (((se - proj) ** 2).sum(-1) + 1e-8) + 1e-8)
+    assert np.allclose(audio.si_snr(torch.from_numpy(t), torch.from_numpy(e)).numpy(), want, atol=1e-4)

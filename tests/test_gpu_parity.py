@@ -403,3 +403,26 @@ def test_step_chunk_pipeline_knob_is_exact():
         del os.environ["S5FXP_CHUNKS"]
     ref, _, _, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
     assert np.array_equal(y.numpy(), ref)
+
+
+def test_denoise_pipeline_on_device_uses_the_exact_model():
+    """fxprun.py:63-78 on the device: STFT -> fixed-point model -> mask -> iSTFT.  The model's part must be the
+    oracle's output for the integer input the pipeline built; the rest is float tensor code checked against scipy in
+    the CPU suite."""
+    import torch
+    from sparsernns_amd import audio
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    g = torch.Generator().manual_seed(5)
+    noisy = (0.02 * torch.randn(2, 128 * 63, generator=g)).cuda()  # 64 STFT frames
+    ib, ie = qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"]
+    cleaned, cleaned_mag, mag = audio.denoise(model, ib, ie, noisy)
+    assert cleaned.shape == noisy.shape and torch.isfinite(cleaned).all()
+    x = (mag - audio.STFT_MAG_MEAN).transpose(-1, -2).contiguous().cpu().numpy()
+    fx = O.from_fp(x, ib, ie, True, O.FLOOR)
+    ref, rb, re_, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
+    mask = torch.from_numpy(ref.astype(np.float32) / (1 << re_)).transpose(-1, -2).cuda()
+    assert torch.equal(cleaned_mag, mag * (1.0 + mask))
+    assert torch.isfinite(audio.si_snr(noisy, cleaned)).all()
