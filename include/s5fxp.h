@@ -65,6 +65,13 @@ int s5fxp_change_cfg(const int32_t *x, int32_t *y, int64_t n, int bits, int exp,
 int s5fxp_dense(const int32_t *x, const int32_t *w, const int32_t *bias, int32_t *y, int64_t N, int K, int M,
                 int x_exp, int w_exp, int b_bits, int b_exp, int out_bits, int out_exp, int flags, void *stream);
 
+/* The same layer with a pruned weight (the reference keeps pruned kernels dense with zeros, jaxpruner masks;
+ * fxparray.py:662 sums them anyway): the (K,M) kernel stored by output channel -- CSR of kernel^T: rowptr[M+1],
+ * colidx[nnz] = k, val[nnz] -- all device int32.  Bit-identical to s5fxp_dense on the densified weight. */
+int s5fxp_dense_csr(const int32_t *x, const int32_t *rowptr, const int32_t *colidx, const int32_t *val,
+                    const int32_t *bias, int32_t *y, int64_t N, int K, int M, int x_exp, int w_exp, int b_bits, int b_exp,
+                    int out_bits, int out_exp, int flags, void *stream);
+
 /* fxp_add with a numeric result_exp, fxparray.py:449-466.  y_len == n (same shape) or a divisor
  * of n (trailing-axis broadcast, e.g. a bias vector). */
 int s5fxp_add(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_bits, int x_exp,
@@ -163,10 +170,12 @@ typedef struct {
 /* Bytes of device memory the packed parameter blob needs. */
 size_t s5fxp_model_blob_bytes(const s5fxp_model_desc *desc);
 
-/* Packs the integer parameters (int8 weights where they fit, CSR for pruned tensors) into
+/* Packs the integer parameters (int8 weight planes for the MFMA path, int32 for the generic one) into
  * `dev_blob` (device, blob_bytes) with a stream-ordered copy and returns a host handle that keeps
  * the scalars.  flags: S5FXP_MODEL_* below.  Returns S5FXP_EUNSUPPORTED for shapes outside the
- * kernels' limits. */
+ * kernels' limits.  Pruned models run the dense kernels on their zero-filled weights (bit-exact; on the MFMA path
+ * the weights live in registers and the contraction is ~2 us per kernel): S5FXP_MODEL_FORCE_DENSE is the default
+ * behaviour, S5FXP_MODEL_FORCE_CSR is refused (EUNSUPPORTED) -- the CSR kernel exists at op level, s5fxp_dense_csr. */
 enum { S5FXP_MODEL_DEFAULT = 0, S5FXP_MODEL_FORCE_DENSE = 1, S5FXP_MODEL_FORCE_CSR = 2, S5FXP_MODEL_FORCE_GENERIC = 4 };
 int s5fxp_model_create(const s5fxp_model_desc *desc, void *dev_blob, size_t blob_bytes, int flags, void *stream,
                        s5fxp_model **out);

@@ -89,6 +89,7 @@ def _load():
         "s5fxp_to_float": (i, [p, p, i64, i, p]),
         "s5fxp_change_cfg": (i, [p, p, i64, i, i, i, i, p]),
         "s5fxp_dense": (i, [p, p, p, p, i64, i, i, i, i, i, i, i, i, i, p]),
+        "s5fxp_dense_csr": (i, [p, p, p, p, p, p, i64, i, i, i, i, i, i, i, i, i, p]),
         "s5fxp_add": (i, [p, p, p, i64, i64, i, i, i, i, i, i, i, p]),
         "s5fxp_mul": (i, [p, p, p, i64, i64, i, i, i, i, p]),
         "s5fxp_add_cb": (i, [p, p, p, i64, i64, i, i, i, i, i, p, p, p]),
@@ -112,7 +113,7 @@ def _load():
 
 
 lib = _load()
-EXPORTED_SYMBOLS = ("s5fxp_version s5fxp_strerror s5fxp_from_fp s5fxp_to_float s5fxp_change_cfg s5fxp_dense s5fxp_add "
+EXPORTED_SYMBOLS = ("s5fxp_version s5fxp_strerror s5fxp_from_fp s5fxp_to_float s5fxp_change_cfg s5fxp_dense s5fxp_dense_csr s5fxp_add "
                     "s5fxp_mul s5fxp_add_cb s5fxp_mul_cb s5fxp_relu s5fxp_sigmoid s5fxp_scan s5fxp_model_blob_bytes "
                     "s5fxp_model_create s5fxp_model_destroy s5fxp_workspace_bytes s5fxp_model_forward "
                     "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast").split()

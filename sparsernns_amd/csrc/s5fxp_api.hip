@@ -129,6 +129,27 @@ extern "C" int s5fxp_dense(const int32_t *x, const int32_t *w, const int32_t *bi
     return launch_rc();
 }
 
+extern "C" int s5fxp_dense_csr(const int32_t *x, const int32_t *rowptr, const int32_t *colidx, const int32_t *val,
+                               const int32_t *bias, int32_t *y, int64_t N, int K, int M, int x_exp, int w_exp, int b_bits,
+                               int b_exp, int out_bits, int out_exp, int flags, void *stream)
+{
+    if (!x || !rowptr || !y || N < 0 || K < 1 || M < 1 || out_bits < 1 || out_bits > 32) return S5FXP_EBADARG;
+    if (!colidx || !val) return S5FXP_EBADARG;
+    const size_t smem = (size_t)(64 * (K | 1) + 64 * 65) * 4;
+    if (smem > 160 * 1024) return S5FXP_EUNSUPPORTED; // K <= 574: the input tile must fit one CU's LDS
+    if (!shift_ok(x_exp + w_exp - out_exp)) return S5FXP_ENEGSHIFT;
+    if (bias && !shift_ok(b_exp > out_exp ? b_exp - out_exp : out_exp - b_exp)) return S5FXP_ENEGSHIFT;
+    if (N == 0) return S5FXP_OK;
+    DenseCsrArgs a{};
+    a.x = x; a.rowptr = rowptr; a.colidx = colidx; a.val = val; a.bias = bias; a.y = y; a.N = N; a.K = K; a.M = M;
+    a.rs = x_exp + w_exp - out_exp; a.b_bits = b_bits; a.b_exp = b_exp; a.out_bits = out_bits; a.out_exp = out_exp;
+    a.relu = flags & 1;
+    if (smem > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_csr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k_dense_csr, dim3((unsigned)((N + 63) / 64)), dim3(256), smem, S(stream), a);
+    return launch_rc();
+}
+
 extern "C" int s5fxp_add(const int32_t *x, const int32_t *y, int32_t *out, int64_t n, int64_t y_len, int x_bits,
                          int x_exp, int y_bits, int y_exp, int out_bits, int out_exp, int negate_y, void *stream)
 {
@@ -416,6 +437,7 @@ extern "C" int s5fxp_model_create(const s5fxp_model_desc *desc, void *dev_blob, 
 {
     if (!out || !dev_blob) return S5FXP_EBADARG;
     *out = nullptr;
+    if (flags & S5FXP_MODEL_FORCE_CSR) return S5FXP_EUNSUPPORTED; // see include/s5fxp.h: op level only
     int rc = validate(desc);
     if (rc) return rc;
     const size_t need = s5fxp_model_blob_bytes(desc);

@@ -270,6 +270,63 @@ __device__ __forceinline__ void mm_stage_out(int32_t (*out)[4 * MWMAX + 1], cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pruned dense layer: fxp_matmul (+ bias, ReLU) with the (K,M) weight stored by output channel -- CSR of the
+// transposed kernel: rowptr[M+1], colidx (the k of every non-zero), val.  int32 sums wrap modulo 2^32 whatever the
+// order of the terms, so skipping the zeros changes nothing (fxparray.py:662).
+// A workgroup owns 64 frames: the whole (64,K) input tile goes to LDS once (row stride odd: conflict-free column
+// reads); a wave takes one output channel at a time, lane = frame, and walks that channel's non-zeros -- the
+// (k, value) pairs are wave-uniform, so they come through the scalar cache.  Results are staged [frame][64 channels]
+// and stored with lanes over channels.  LDS: [x 64 x (K|1)] [out 64 x 65].
+// On MI355X this is for operands the int8 MFMA path cannot take (activations beyond 16 bit, arbitrary shapes): there
+// the weights live in registers and the dense contraction costs ~2 us per kernel, which no sparse format can beat.
+// ---------------------------------------------------------------------------------------------
+struct DenseCsrArgs {
+    const int32_t *x;                       // (N,K)
+    const int32_t *rowptr, *colidx, *val;   // by output channel
+    const int32_t *bias;                    // (M) or null
+    int32_t *y;                             // (N,M)
+    int64_t N;
+    int32_t K, M;
+    int32_t rs, b_bits, b_exp, out_bits, out_exp, relu;
+};
+
+__global__ __launch_bounds__(256) void k_dense_csr(DenseCsrArgs a)
+{
+    extern __shared__ int32_t csr_smem[];
+    const int KS = a.K | 1;
+    int32_t *xs = csr_smem, *out = csr_smem + 64 * KS;
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int e = threadIdx.x; e < 64 * a.K; e += 256) {
+        const int nl = e / a.K, k = e - nl * a.K;
+        const int64_t n = n0 + nl;
+        xs[nl * KS + k] = n < a.N ? a.x[n * a.K + k] : 0;
+    }
+    __syncthreads();
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        for (int mj = wave; mj < 64 && m0 + mj < a.M; mj += 4) {
+            const int m = m0 + mj;
+            const int t0 = a.rowptr[m], t1 = a.rowptr[m + 1];
+            int32_t acc = 0;
+            for (int t = t0; t < t1; ++t) acc = wadd(acc, wmul(xs[lane * KS + a.colidx[t]], a.val[t]));
+            out[lane * 65 + mj] = acc;
+        }
+        __syncthreads();
+        for (int nl = wave; nl < 64; nl += 4) {
+            const int64_t n = n0 + nl;
+            const int m = m0 + lane;
+            if (n < a.N && m < a.M) {
+                int32_t v = sat(asr(out[nl * 65 + lane], a.rs), a.out_bits);
+                if (a.bias) v = sat(wadd(v, chexp(a.bias[m], a.b_bits, a.b_exp, a.out_exp)), a.out_bits);
+                if (a.relu) v = v < 0 ? 0 : v;
+                a.y[n * a.M + m] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dense: FxpDense.forward (fxpmodel.py:331-366) [+ ReLU fxpmodel.py:53-63].
 // ---------------------------------------------------------------------------------------------
 struct DenseArgs {

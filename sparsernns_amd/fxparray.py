@@ -365,6 +365,42 @@ def fxp_matmul(op1, op2, result_bits: Optional[int] = None, result_bits_fn: Call
     return FxpArray(y, result_bits, int(result_exp), True)
 
 
+class CsrWeight:
+    """A pruned (K,M) kernel stored by output channel (CSR of kernel^T) on the device, for ``fxp_matmul_csr``."""
+
+    def __init__(self, w: np.ndarray, bits: int, exp: int, device=None):
+        w = np.asarray(w, dtype=np.int32)
+        self.K, self.M, self.bits, self.exp = int(w.shape[0]), int(w.shape[1]), int(bits), int(exp)
+        wt = w.T
+        nz = wt != 0
+        self.nnz = int(nz.sum())
+        rowptr = np.zeros(self.M + 1, dtype=np.int32)
+        rowptr[1:] = np.cumsum(nz.sum(axis=1))
+        cols = np.nonzero(nz)[1].astype(np.int32)
+        vals = wt[nz].astype(np.int32)
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rowptr = torch.from_numpy(rowptr).to(dev)
+        self.colidx = torch.from_numpy(cols if self.nnz else np.zeros(1, np.int32)).to(dev)
+        self.val = torch.from_numpy(vals if self.nnz else np.zeros(1, np.int32)).to(dev)
+
+    @property
+    def density(self) -> float:
+        return self.nnz / float(self.K * self.M)
+
+
+def fxp_matmul_csr(op1: FxpArray, op2: CsrWeight, result_bits: int, result_exp: int) -> FxpArray:
+    """fxp_matmul (:640-678) with a pruned kernel: bit-identical to the dense op on the zero-filled kernel."""
+    _signed_only(op1)
+    if op1.shape[-1] != op2.K:
+        raise ValueError(f"fxp_matmul_csr shapes {op1.shape} @ ({op2.K}, {op2.M})")
+    x = op1.data.contiguous()
+    N = x.numel() // op2.K
+    y = torch.empty(tuple(x.shape[:-1]) + (op2.M,), dtype=torch.int32, device=x.device)
+    check(lib.s5fxp_dense_csr(_ptr(x), _ptr(op2.rowptr), _ptr(op2.colidx), _ptr(op2.val), None, _ptr(y), N, op2.K, op2.M,
+                              op1.exp, op2.exp, 0, 0, result_bits, int(result_exp), 0, _stream()), "fxp_matmul_csr")
+    return FxpArray(y, result_bits, int(result_exp), True)
+
+
 def fxp_isvalid(arr: FxpArray, do_warn: bool = False) -> bool:  # :704-721
     if arr.data is None or arr.bits <= 0 or arr.exp < 0:
         return False

@@ -213,10 +213,14 @@ class HostComplexFxp:
     imag: HostFxp
 
 
+CSR_DENSITY = 0.25  # kernels at or below this density use s5fxp_dense_csr in op-by-op mode
+
+
 @dataclass
 class FxpDense(FxpModule):  # :291-393
     weight: Optional[HostFxp] = None
     bias: Optional[HostFxp] = None
+    _csr: Optional[object] = None
 
     def setup(self):
         q = self.fxp_qconfig
@@ -233,7 +237,13 @@ class FxpDense(FxpModule):  # :291-393
         fx = _fx()
         if (x.bits > self.inp_bits) or (x.exp > self.inp_exp):
             x = x.change_cfg(new_bits=self.inp_bits, new_exp=self.inp_exp, new_signed=True)
-        wx = fx.fxp_matmul(x, self.weight.dev(), result_bits=self.out_bits, result_exp=self.out_exp)
+        # op-by-op mode only (the fused engine keeps weights in registers): a pruned kernel goes through the CSR op
+        if self._csr is None and np.count_nonzero(self.weight.data) <= CSR_DENSITY * self.weight.data.size:
+            self._csr = fx.CsrWeight(self.weight.data, self.weight_bits, self.weight_exp)
+        if self._csr is not None:
+            wx = fx.fxp_matmul_csr(x, self._csr, result_bits=self.out_bits, result_exp=self.out_exp)
+        else:
+            wx = fx.fxp_matmul(x, self.weight.dev(), result_bits=self.out_bits, result_exp=self.out_exp)
         if self.bias is not None:
             wx = fx.fxp_add(wx, self.bias.dev(), result_bits=self.out_bits, result_exp=self.out_exp)
         self.sow("intermediates", "__call__", wx)
