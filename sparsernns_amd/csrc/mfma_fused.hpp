@@ -9,6 +9,8 @@
 
 namespace s5 {
 
+using v2i16 = __attribute__((ext_vector_type(2))) short;
+
 struct CGateArgs {
     const int16_t *u;    // (N,H) SSM input (written by the B projection)
     const int16_t *skip; // (N,H) layer input
@@ -78,7 +80,9 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
 
 constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checked)
 
-template <int KS, int NT, bool TRACE>
+// S16: the state stream holds int16, written with saturation by k_scan_quad_asm16 (a.xmax <= 32766 then: a saturated
+// state fails the range check like any other state beyond the bound)
+template <int KS, int NT, bool TRACE, bool S16 = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
 {
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
     const int cv_b1 = a.conv && a.inp_exp != a.y_exp ? a.y_bits : 32, cv_b2 = a.conv && a.y_bits > a.inp_bits ? a.inp_bits : 32;
     const int cv_b = cv_b1 < cv_b2 ? cv_b1 : cv_b2;
     uint32_t xrange = 0;
+    v2i16 pmax = {0, 0}, pmin = {0, 0}; // S16: running extremes of (re, im) as packed int16
     float mx[3] = {0.f, 0.f, 0.f}; // |z*kz + s|, |z|, |s| as converted integers; scaled once at the end
     const int ch0 = 32 * ct + 4 * h;
     __syncthreads();
@@ -152,9 +157,24 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
                 const int grp = q / P, p = q % P;
                 int o = 4 * grp;
                 if (o >= nvalid) o = nvalid - 4; // partial tile: re-read the last block (results unused)
+                int32_t w[4];
+                if (S16) {
+                    // 16 bytes: re of steps 0..3, then im of steps 0..3, as int16; w[j] = re_j | im_j << 16 by two perms
+                    const v4i q4 = *reinterpret_cast<const v4i *>(reinterpret_cast<const int16_t *>(a.xs) + native_word(b0, t0 + o, p, 0, a.TB, P));
+                    w[0] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x05040100u);
+                    w[1] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x07060302u);
+                    w[2] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x05040100u);
+                    w[3] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x07060302u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(v2i16, w[j]));
+                        pmin = __builtin_elementwise_min(pmin, __builtin_bit_cast(v2i16, w[j]));
+                        const bool keep = ((int32_t)((uint32_t)w[j] << 16) > 0) | ((((uint32_t)w[j] & 0xffffu) == 0) & (w[j] > 0));
+                        w[j] = keep ? w[j] : 0;
+                    }
+                } else {
                 const int32_t *src = a.xs + native_word(b0, t0 + o, p, 0, a.TB, P);
                 const v4i cre = *reinterpret_cast<const v4i *>(src), cim = *reinterpret_cast<const v4i *>(src + 4);
-                int32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int32_t xr = cre[j], xi = cim[j];
@@ -164,6 +184,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
                     // complex ReLU = lexicographic max(z, 0); exact in integers while |x| <= xmax < 2^24
                     const bool keep = (xr > 0) | ((xr == 0) & (xi > 0));
                     w[j] = keep ? (int32_t)perm((unsigned)xi, (unsigned)xr, 0x05040100u) : 0;
+                }
                 }
                 quad_transpose(w, l);
                 // now: this lane = frame 4*grp + (l&3), w[m] = (re | im << 16) of state (p & ~3) + m
@@ -272,6 +293,10 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
         }
     }
     // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
+    if (S16) {
+        const int hi = pmax[0] > pmax[1] ? pmax[0] : pmax[1], lo = pmin[0] < pmin[1] ? pmin[0] : pmin[1];
+        if (hi > a.xmax || lo < -a.xmax) xrange = 0xffffffffu;
+    }
     if (__any(xrange > 2u * (uint32_t)a.xmax) && l == 0) {
         atomicExch(&a.dynw->redo, 1);
         atomicOr(a.status, a.bad_bits);

@@ -45,7 +45,9 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
     nvalid = sr.t_len - tt < 64 ? sr.t_len - tt : 64;
 }
 
-template <int KS, int NT, bool TRACE>
+// S16: the stream holds int16 (the host has checked that every value fits: Bu bits minus the shift to the state
+// exponent <= 16); one item is then 8 bytes
+template <int KS, int NT, bool TRACE, bool S16 = false>
 __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
 {
     constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
@@ -162,7 +164,11 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }
                         }
-                        *reinterpret_cast<v4i *>(a.bq + native_word(b0, t0 + o, p, cc, a.TB, PC)) = q;
+                        if (S16)
+                            *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
+                                pack4_i16(q[0], q[1], q[2], q[3]);
+                        else
+                            *reinterpret_cast<v4i *>(a.bq + native_word(b0, t0 + o, p, cc, a.TB, PC)) = q;
                     }
                 }
             }

@@ -372,6 +372,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
         // ---- B projection -> scan-native stream (+ u for the C projection)
         const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
+        const bool quad = l.quad_ok && !exact;
+        // optimistic forwards (the caller repeats with S5FXP_FWD_EXACT if the range check fires) keep both recurrence
+        // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
+        // B projection's output, of both sides of the recurrence and of the gate kernel's state input
+        const bool s16 = defer && quad && !tr && n_chunks == 1 && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
         {
             BprojM2Args a{};
             a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
@@ -389,6 +394,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 if (tr) {
                     if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a);
                     else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a);
+                } else if (s16) {
+                    if (big) launch_smem(k_bproj_p<6, 8, false, true>, pgrid, smem, st, a);
+                    else launch_smem(k_bproj_p<3, 4, false, true>, pgrid, smem, st, a);
                 } else {
                     if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a);
                     else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a);
@@ -402,7 +410,6 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = 32767; // the C projection's 16-bit planes
-        const bool quad = l.quad_ok && !exact;
         const bool piped = quad && n_chunks > 1;
         hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
         if (piped && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[0], 0)))) return rc;
@@ -417,10 +424,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     q.tb0 = c_lo[k] / 4;
                     q.ntb = k + 1 < n_chunks ? (c_lo[k + 1] - c_lo[k]) / 4 : 0; // the last chunk runs to the padded end
                 }
-                hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
+                if (s16) hipLaunchKernelGGL(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
+                else hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
                 if (piped && (rc = hip_rc(hipEventRecord(F.pipe.ev_s[k], sst)))) return rc;
             }
             xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
+            if (s16 && xmax > 32766) xmax = 32766; // a saturated int16 state must fail the check
         } else {
             sl.run_if = nullptr;
             hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
@@ -474,6 +483,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
+                    } else if (s16) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true>, cg, smem, a);
+                        else launch6g(k_cgate_p<2, 3, false, true>, cg, smem, a);
                     } else {
                         if (big) launch6g(k_cgate_p<4, 6, false>, cg, smem, a);
                         else launch6g(k_cgate_p<2, 3, false>, cg, smem, a);

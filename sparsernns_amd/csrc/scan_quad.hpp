@@ -167,4 +167,43 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
                  : S5_SCAN_ASM_CLOBBERS);
 }
 
+// int16 streams (S5FXP_FWD_DEFER_REDO forwards, where the caller checks the status words): the same chain; the
+// input halfword is picked by the SDWA source select, the output is packed with saturation -- a state beyond 16 bits
+// is stored as +-32767 / -32768, which the consumer's range check treats as out of range.  Half the bytes of
+// k_scan_quad_asm on both sides; item = 8 bytes (4 steps of one component), state block = 16 bytes.
+__global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+    const int groups = a.P >> 4;
+    const int b = wave / groups, p0 = (wave % groups) << 4;
+    if (b >= a.B) return;
+    const int s = lane >> 2, r = lane & 3;
+    const int p = p0 + s;
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int sre = 16 - a.ea_re, sim = 16 - a.ea_im;
+    const int32_t kre = (1 << 16) - (1 << sre);
+    int32_t cA, cB, kA = 0, kB = 0;
+    if (r == 0) { cA = cB = Ar << sre; }
+    else if (r == 1) { cA = cB = Ar << sim; }
+    else if (r == 2) { cA = -(Ai << sre); kA = kre; cB = Ai << sim; }
+    else { cA = Ai << sim; cB = -(Ai << sre); kB = kre; }
+    const int32_t x0 = 0;
+    const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // halfwords
+    const unsigned blk_stride = (unsigned)a.P * 16u;
+    const unsigned extent = (unsigned)a.TB * blk_stride;
+    const unsigned long long bin = (unsigned long long)(reinterpret_cast<const int16_t *>(a.bq) + wave_off),
+                             bout = (unsigned long long)(reinterpret_cast<int16_t *>(a.xs) + wave_off);
+    u32x4 rin, rout;
+    rin[0] = (unsigned)bin; rin[1] = (unsigned)(bin >> 32) & 0xffffu; rin[2] = extent; rin[3] = 0x00020000u;
+    rout[0] = (unsigned)bout; rout[1] = (unsigned)(bout >> 32) & 0xffffu; rout[2] = extent; rout[3] = 0x00020000u;
+    const unsigned voff = r < 2 ? (unsigned)(s * 16 + r * 8) : 0xFFFFFF00u;
+    unsigned sld = 0, sst = 0, cnt = (unsigned)a.TB / S5_SCAN_ASM_DEPTH;
+    asm volatile(S5_SCAN16_ASM_BODY
+                 : [sld] "+s"(sld), [sst] "+s"(sst), [cnt] "+s"(cnt)
+                 : [ca] "v"(cA), [cb] "v"(cB), [ka] "v"(kA), [kb] "v"(kB), [voff] "v"(voff), [x0] "v"(x0), [rin] "s"(rin),
+                   [rout] "s"(rout), [stride] "s"(blk_stride)
+                 : S5_SCAN16_ASM_CLOBBERS);
+}
+
 } // namespace s5
