@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(B, L, P):
+def pmc_traffic(B, L, P, kernel):
     """HBM bytes per recurrence launch from the committed PMC passes (profiles/r01_scan_traffic.json: FETCH_SIZE
     doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), if they were taken on this workload."""
     p = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
@@ -37,7 +37,9 @@ def pmc_traffic(B, L, P):
         return None
     with open(p) as f:
         t = json.load(f)
-    return t["traffic_bytes_per_launch"] if (t["B"], t["L"], t["P"]) == (B, L, P) else None
+    if (t["B"], t["L"], t["P"]) != (B, L, P) or kernel not in t["kernels"]:
+        return None
+    return t["kernels"][kernel]["traffic_bytes_per_launch"]
 
 
 def main() -> None:
@@ -198,10 +200,16 @@ def main() -> None:
     scan_avg_s = scan_avg(ev1) if depth > 1 else scan_inflight_s
     algo_bytes = B * L * dims["P"] * 16
     achieved = algo_bytes / scan_avg_s / 1e9
-    roofline = dict(bound="hbm", kernel="k_scan_quad_asm (the S5 recurrence)", achieved=round(achieved, 1),
+    # optimistic forwards (everything but --self-contained / mode A) run the int16-stream variant of the kernel: the
+    # algorithmic bytes stay SURVEY.md 8(d)'s 16*P per frame (the reference's int32 element type); what the kernel
+    # actually moves is in `traffic` (PMC) and `stored_bytes_per_launch`
+    optimistic = not (allreduce or args.self_contained)
+    scan_kernel = "k_scan_quad_asm16" if optimistic else "k_scan_quad_asm"
+    roofline = dict(bound="hbm", kernel=scan_kernel + " (the S5 recurrence)", achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=pmc_traffic(B, L, dims["P"]), avg_kernel_us=round(scan_avg_s * 1e6, 2),
+                    traffic=pmc_traffic(B, L, dims["P"], scan_kernel), avg_kernel_us=round(scan_avg_s * 1e6, 2),
                     algorithmic_bytes_per_launch=algo_bytes,
+                    stored_bytes_per_launch=algo_bytes // 2 if optimistic else algo_bytes,
                     measured=("HIP events around every launch, one layer per step, " +
                               ("in the one-at-a-time pass of the same K steps" if depth > 1 else "in the timed region")),
                     avg_kernel_us_sharing_the_gpu=round(scan_inflight_s * 1e6, 2) if depth > 1 else None)
