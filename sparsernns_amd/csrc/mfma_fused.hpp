@@ -45,7 +45,8 @@ __global__ void k_select_maxima(LayerDyn *d)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phase-split version (see proj_p.hpp for the idea).  Workgroup = six waves, tile = 64 frames:
+// Phase-split version (see proj_p.hpp for the idea).  Workgroup = one wave per (32-frame half, 32-channel tile): six
+// waves at H=96, twelve at H=192; tile = 64 frames:
 //   A   all threads: one 32-byte stream item (state p, 4 steps, re+im) per thread -> range check, complex
 //       ReLU, 4x4 transpose inside the lane quad (DPP) so that a lane holds 4 consecutive states of ONE
 //       frame -> byte planes S[frame][re P | im P] in LDS;
@@ -54,7 +55,7 @@ __global__ void k_select_maxima(LayerDyn *d)
 //   B2  the same wave: out2 for the same channels/frames from the X1 planes (natural k order), LUT sigmoid,
 //       gate, int16 store, residual maxima.
 // No weights in LDS (35 KB at dim 0.5, 65 KB at dim 1.0), ~128 registers.
-// LDS: [cs_re][cs_im][D][cs_out2][bias_eff] (Np ints each) [lut pairs 8] [S hi][S lo][X1 hi][X1 lo] [red 3x8]
+// LDS: [cs_re][cs_im][D][cs_out2][bias_eff] (Np ints each) [lut pairs 8] [S hi][S lo][X1 hi][X1 lo] [red 3x16]
 // ---------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ int32_t quad_xchg(int32_t v)
@@ -84,13 +85,12 @@ constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checke
 // state fails the range check like any other state beyond the bound)
 template <int KS, int NT, bool TRACE, bool S16 = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
-__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
+__global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
-    constexpr int P = 32 * KS, H = 32 * NT, FT = 64, NW = 6;
+    constexpr int P = 32 * KS, H = 32 * NT, FT = 64, NW = 2 * NT, NTHR = 64 * NW; // one wave per (half, column tile)
     constexpr int KPS = 2 * P + 16, KPX = H + 16;
-    constexpr int NU = 2 * NT / NW;      // (half, column tile) units per wave: 1 (H=96) or 2 (H=192)
-    constexpr int SUBSTEP = NW / NT;     // 2 or 1
-    constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + 383) / 384;
+    constexpr int NU = 1, SUBSTEP = 0;   // units per wave
+    constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
     int32_t *sigt = lutp + 8; // SIGTAB_WORDS
@@ -113,11 +113,11 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
 #pragma unroll
         for (int ks = 0; ks < NT; ++ks) wo2[ks] = *reinterpret_cast<const v4i *>(a.w_o2.wt + row * a.w_o2.Kp + 32 * ks + 16 * h);
     }
-    for (int i = threadIdx.x; i < H; i += 384) {
+    for (int i = threadIdx.x; i < H; i += NTHR) {
         csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i]; be[i] = a.bias_eff[i];
     }
     if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
-    for (int i = threadIdx.x; i < (14 << a.sig_x); i += 384) sigt[i] = a.sigtab[i];
+    for (int i = threadIdx.x; i < (14 << a.sig_x); i += NTHR) sigt[i] = a.sigtab[i];
     const int skip_e = a.skip_e.get();
     const float kz = ldexpf(1.f, skip_e - a.res_exp); // fz + fs = 2^-skip_e * (z * kz + s), exactly
     const int sx = a.sig_x, S = 1 << sx;
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
         // ---- phase A: stream items -> byte planes
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
-            const int q = threadIdx.x + 384 * i;
-            if (ROUNDS * 384 == ITEMS || q < ITEMS) {
+            const int q = threadIdx.x + NTHR * i;
+            if (ROUNDS * NTHR == ITEMS || q < ITEMS) {
                 const int grp = q / P, p = q % P;
                 int o = 4 * grp;
                 if (o >= nvalid) o = nvalid - 4; // partial tile: re-read the last block (results unused)
@@ -309,12 +309,12 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_cgate_p(CGateArgs a)
         float x = mx[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-        if (l == 0) red[i * 8 + wave] = x;
+        if (l == 0) red[i * 16 + wave] = x;
     }
     __syncthreads();
     if (threadIdx.x < 3) {
-        float x = red[threadIdx.x * 8];
-        for (int w = 1; w < NW; ++w) x = fmaxf(x, red[threadIdx.x * 8 + w]);
+        float x = red[threadIdx.x * 16];
+        for (int w = 1; w < NW; ++w) x = fmaxf(x, red[threadIdx.x * 16 + w]);
         atomicMax(a.dynw->mx + 8 + threadIdx.x, __float_as_uint(x));
     }
 }

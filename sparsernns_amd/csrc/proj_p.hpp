@@ -5,7 +5,7 @@
 // all column tiles of accumulators) in one wave: 200-256 registers, two waves per SIMD, and every stall of
 // the serial load -> chain -> MFMA -> epilogue sequence is exposed.  Here a workgroup of four waves owns a
 // tile of 64 frames:
-//   phase A  all 256 threads: 16-byte coalesced loads of the (64,H) int16 tile, the BatchNorm chain on eight
+//   phase A  all threads: 16-byte coalesced loads of the (64,H) int16 tile, the BatchNorm chain on eight
 //            channels per vector, u stored with 16-byte coalesced stores, byte planes into LDS [frame][k];
 //   phase B  wave w: column tile w of the matmul for both 32-frame halves.  The MFMA runs as D = X * W
 //            (A operand = byte planes from LDS, B operand = this wave's weight columns, held in registers for
@@ -48,14 +48,15 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
 // S16: the stream holds int16 (the host has checked that every value fits: Bu bits minus the shift to the state
 // exponent <= 16); one item is then 8 bytes
 template <int KS, int NT, bool TRACE, bool S16 = false>
-__global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
+__global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
 {
     constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
     constexpr int VPF = H / 8;             // 16-byte vectors per frame
-    constexpr int NV = FT * VPF / 256;     // vectors per thread and tile
-    constexpr int NCT = NT / 4;            // column tiles per wave
+    constexpr int NTHR = 64 * NT;          // one wave per column tile: 256 threads at dim 0.5, 512 at dim 1.0
+    constexpr int NV = FT * VPF / NTHR;    // vectors per thread and tile
+    constexpr int NCT = 1;                 // column tiles per wave
     constexpr int PLANE = FT * KP;
-    static_assert(FT * VPF % 256 == 0 && NT % 4 == 0, "tile shape");
+    static_assert(FT * VPF % NTHR == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *tab = reinterpret_cast<int32_t *>(smem);             // 4*H BatchNorm operands
     int8_t *Xh = smem + 16 * H, *Xl = Xh + 2 * PLANE;             // [buf][frame][KP]
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
         tile_of(tl, sr, b, t, nv);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = threadIdx.x + 256 * i;
+            const int v = threadIdx.x + NTHR * i;
             int f = v / VPF;
             f = f < nv ? f : nv - 1;
             raw[i] = *reinterpret_cast<const v4i *>(a.x + (b * a.L + t + f) * H + 8 * (v % VPF));
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
     int32_t csv[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int col = 32 * (wave + 4 * c) + r;
+        const int col = 32 * (wave + NT * c) + r;
         csv[c] = a.w.cs128[col];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
         // ---- phase A: BatchNorm chain, u, byte planes
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = threadIdx.x + 256 * i, f = v / VPF, og = v % VPF;
+            const int v = threadIdx.x + NTHR * i, f = v / VPF, og = v % VPF;
             const int64_t n = n0 + f;
             int32_t xin[8], t[8], u[8];
             unpack8_i16(raw[i], xin);
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, KS <= 3 ? 4 : 2) void k_bproj_p(BprojM2Args a)
         // ---- phase B: this wave's column tile(s), both 32-frame halves
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
-            const int col = 32 * (wave + 4 * c) + r;
+            const int col = 32 * (wave + NT * c) + r;
             const int cc = col >= PC ? 1 : 0, p = col - cc * PC;
             const int rs = cc ? a.rs_im : a.rs_re, bits = cc ? a.bim_bits : a.bre_bits, sh = cc ? a.sh_im : a.sh_re;
             const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;

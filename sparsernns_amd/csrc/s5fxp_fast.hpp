@@ -204,11 +204,11 @@ FastWs fast_ws(const s5fxp_model *m, int B, int L)
 }
 
 template <class K, class A>
-inline void launch_smem(K kernel, unsigned grid, size_t smem, hipStream_t st, const A &args)
+inline void launch_smem(K kernel, unsigned grid, size_t smem, hipStream_t st, const A &args, unsigned threads = 256)
 {
     if (smem > 65536) // the dim_scale 1.0 tiles need more than the default dynamic-LDS limit
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), smem, st, args);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, st, args);
 }
 
 // one workgroup = 4 waves x 32 frames; cap the grid at 4 workgroups per CU and let waves loop
@@ -254,10 +254,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles, two workgroups per CU
     const int64_t tiles64 = (N + 63) / 64, per6 = (tiles64 + 511) / 512;
     const unsigned grid6 = (unsigned)((tiles64 + per6 - 1) / per6);
-    auto launch6g = [&](auto kernel, unsigned g6, size_t smem, const auto &args) {
+    auto launch6g = [&](auto kernel, unsigned g6, size_t smem, const auto &args, unsigned threads = 384) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kernel, dim3(g6), dim3(384), smem, st, args);
+        hipLaunchKernelGGL(kernel, dim3(g6), dim3(threads), smem, st, args);
     };
     auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid6, smem, args); };
     auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, const ResidTail &tl) {
@@ -390,16 +390,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             for (int k = 0; k < n_chunks; ++k) {
                 a.t_lo = c_lo[k]; a.t_len = c_lo[k + 1] - c_lo[k];
                 const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? 512 : 1024, per = (tl + cap - 1) / cap;
+                const unsigned bthr = big ? 512 : 256; // one wave per 32-column tile of [B_re | B_im]
                 const unsigned pgrid = (unsigned)((tl + per - 1) / per);
                 if (tr) {
-                    if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a);
-                    else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a);
+                    if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr);
                 } else if (s16) {
-                    if (big) launch_smem(k_bproj_p<6, 8, false, true>, pgrid, smem, st, a);
-                    else launch_smem(k_bproj_p<3, 4, false, true>, pgrid, smem, st, a);
+                    if (big) launch_smem(k_bproj_p<6, 8, false, true>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, false, true>, pgrid, smem, st, a, bthr);
                 } else {
-                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a);
-                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a);
+                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr);
                 }
                 if (n_chunks > 1 && (rc = hip_rc(hipEventRecord(F.pipe.ev_b[k], st)))) return rc;
             }
@@ -469,7 +470,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
-            const size_t smem = 5 * (size_t)H * 4 + 32 + 4 * SIGTAB_WORDS + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 96;
+            const size_t smem = 5 * (size_t)H * 4 + 32 + 4 * SIGTAB_WORDS + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
@@ -481,13 +482,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + 511) / 512;
                     const unsigned cg = (unsigned)((tl + per - 1) / per);
                     if (tr) {
-                        if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a);
+                        if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
                     } else if (s16) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true>, cg, smem, a);
+                        if (big) launch6g(k_cgate_p<4, 6, false, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, false, true>, cg, smem, a);
                     } else {
-                        if (big) launch6g(k_cgate_p<4, 6, false>, cg, smem, a);
+                        if (big) launch6g(k_cgate_p<4, 6, false>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, false>, cg, smem, a);
                     }
                 }
