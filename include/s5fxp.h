@@ -203,7 +203,9 @@ enum {
  * the exact 32-bit kernels, gated on a device flag, so the output is right whatever the data.  A caller that
  * reads the status words anyway can drop those (normally idle) launches:
  *   DEFER_REDO  do not enqueue the gated exact kernels; S5FXP_ST_REDO in status[0] tells the caller to repeat
- *               the forward with S5FXP_FWD_EXACT;
+ *               the forward with S5FXP_FWD_EXACT.  The recurrence streams are then kept as int16 where the model's
+ *               Bu configuration guarantees they fit (half the bytes; a state beyond 16 bits saturates and raises
+ *               S5FXP_ST_REDO like any other state outside the fast kernels' range);
  *   EXACT       skip the fast recurrence, run the exact kernels only. */
 enum { S5FXP_FWD_DEFER_REDO = 1, S5FXP_FWD_EXACT = 2 };
 
