@@ -253,7 +253,7 @@ def main() -> None:
 
     # ---- CPU baseline: the scalar C oracle ("port") on a bounded sample of the same workload, rank 0 only
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # N=1 only: the host cores belong to one process there
         from oracle import cref
         cb = min(args.cpu_batch, B)
         cm = cref.CModel(model.export())
