@@ -82,8 +82,15 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # S5FXP_BENCH_BACKEND=gloo is a rehearsal aid: several ranks on ONE GPU (RCCL refuses duplicate devices), to
+        # exercise this script's multi-rank branches without a multi-GPU node.  The driver's runs use RCCL.
+        backend = os.environ.get("S5FXP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -188,6 +195,8 @@ def main() -> None:
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if dist.get_backend() != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     frames = B * L * world * args.steps
@@ -246,7 +255,12 @@ def main() -> None:
         out = torch.empty((world,) + tuple(y.shape), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, y)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, y)
+        else:  # rehearsal backend: through the host
+            parts = [torch.empty_like(y, device="cpu") for _ in range(world)]
+            dist.all_gather(parts, y.cpu())
+            out.copy_(torch.stack(parts))
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert torch.equal(out[rank], y)
