@@ -35,6 +35,8 @@ struct CGateArgs {
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
     int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
     const int32_t *sigtab; // [2][7 << sig_x]: gate operand r for a non-positive / positive sigmoid input (k_cgate_p)
+    const int16_t *sigdir; // DIRECT: [1 << sigdir_bits] gate operand r for every value of (gq >> (out_exp - sig_x))
+    int32_t sigdir_bits;
 };
 
 // multi-rank mode only: the residual maxima of a re-run layer live in slots 11..13; move them to 8..10, the
@@ -80,10 +82,13 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
 }
 
 constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checked)
+constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 
 // S16: the state stream holds int16, written with saturation by k_scan_quad_asm16 (a.xmax <= 32766 then: a saturated
 // state fails the range check like any other state beyond the bound)
-template <int KS, int NT, bool TRACE, bool S16 = false>
+// DIRECT: the sigmoid input xx = gq >> (out_exp - sig_x) has only out_bits - (out_exp - sig_x) <= 12 bits, so r is read
+// from a table over xx itself (no |xx|, segment index, remainder or sign logic at all)
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
@@ -93,8 +98,9 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
     constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
-    int32_t *sigt = lutp + 8; // SIGTAB_WORDS
-    int8_t *Sh = reinterpret_cast<int8_t *>(sigt + SIGTAB_WORDS), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
+    int32_t *sigt = lutp + 8; // SIGTAB_WORDS, or the direct table (int16, SIGDIR_BYTES)
+    const int16_t *sigd = reinterpret_cast<const int16_t *>(sigt);
+    int8_t *Sh = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? SIGDIR_BYTES : 4 * SIGTAB_WORDS), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
@@ -117,7 +123,13 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
         csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i]; be[i] = a.bias_eff[i];
     }
     if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
-    for (int i = threadIdx.x; i < (14 << a.sig_x); i += NTHR) sigt[i] = a.sigtab[i];
+    if (DIRECT) {
+        for (int i = threadIdx.x; i < (1 << a.sigdir_bits) / 2; i += NTHR)
+            sigt[i] = reinterpret_cast<const int32_t *>(a.sigdir)[i];
+    } else {
+        for (int i = threadIdx.x; i < (14 << a.sig_x); i += NTHR) sigt[i] = a.sigtab[i];
+    }
+    const int dsh = a.out_exp - a.sig_x, dbias = 1 << (a.sigdir_bits - 1);
     const int skip_e = a.skip_e.get();
     const float kz = ldexpf(1.f, skip_e - a.res_exp); // fz + fs = 2^-skip_e * (z * kz + s), exactly
     const int sx = a.sig_x, S = 1 << sx;
@@ -260,12 +272,15 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
                         // functions of the sign of xx and of (min(|xx| >> sx, 6), |xx| mod 2^sx) only: 2 x 7 x 2^sx
                         // values, tabulated by the host with the same formula (s5fxp_fast.hpp).  The TRACE
                         // instantiation computes s the long way (it has to write it out).
+                        int32_t s = 0, rq;
+                        if (DIRECT) {
+                            rq = sigd[(gq >> dsh) + dbias];
+                        } else {
                         const int32_t xx = chexp(gq, a.out_bits, a.out_exp, sx);
                         const int32_t ax = xx < 0 ? -xx : xx;
                         int32_t ind = ax >> sx;
                         ind = ind > 6 ? 6 : ind;
                         const int32_t mu = ax & (S - 1);
-                        int32_t s = 0, rq;
                         if (TRACE) {
                             const uint32_t pr = (uint32_t)lutp[ind];
                             const int32_t half = (__mul24(S - mu, (int32_t)(pr & 0xffffu)) >> sx) + (__mul24(mu, (int32_t)(pr >> 16)) >> sx);
@@ -273,6 +288,7 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
                             rq = chcfg(s, a.out_bits, a.sig_y, a.r_bits, a.r_exp);
                         } else {
                             rq = sigt[((ind << sx) | mu) + (xx > 0 ? 7 * S : 0)];
+                        }
                         }
                         const int32_t lq = chcfg(x1v[u][4 * g + e], a.y_bits, a.y_exp, a.l_bits, a.l_exp);
                         const int32_t z = sat(asr(__mul24(lq, rq), a.rs_gate), a.res_bits);

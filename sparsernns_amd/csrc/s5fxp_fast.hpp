@@ -13,6 +13,8 @@ struct FastLayer {
     MfmaWDev bproj, cre, cim, out2;
     const int32_t *Dpad = nullptr; // [Np]
     const int32_t *sigtab = nullptr; // [2][7 << sig_x] (mfma_fused.hpp k_cgate_p)
+    const int16_t *sigdir = nullptr; // [1 << sigdir_bits] when the sigmoid input has <= 12 bits (DIRECT)
+    int sigdir_bits = 0;
 };
 
 // The recurrence keeps only B*P/16 waves busy for ~50 us per layer while the projections on either side of it
@@ -168,6 +170,20 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
                 tab[(size_t)pos * 7 * S + i] = chcfg(sg, l.out2.out_bits, sy, l.r_bits, l.r_exp);
             }
         o.sigtab = reinterpret_cast<const int32_t *>(put_raw(p, tab.data(), tab.size() * 4));
+        // the sigmoid input is xx = gq >> (out_exp - sx): when that leaves <= 12 bits, r is tabulated over xx itself
+        const int nb = l.out2.out_bits - (l.out2.out_exp - sx);
+        if (l.out2.out_exp >= sx && nb >= 2 && nb <= SIGDIR_MAX_BITS && l.r_bits <= 16) {
+            std::vector<int16_t> dir((size_t)1 << nb);
+            for (int i = 0; i < (1 << nb); ++i) {
+                const int32_t xx = i - (1 << (nb - 1)), ax = xx < 0 ? -xx : xx;
+                const int ind = (ax >> sx) > 6 ? 6 : (ax >> sx), mu = ax & (S - 1);
+                const int32_t half = wadd(asr(wmul(S - mu, l.lut[ind]), sx), asr(wmul(mu, l.lut[ind + 1]), sx));
+                const int32_t sg = wadd(1 << (sy - 1), xx > 0 ? half : wsub(0, half));
+                dir[i] = (int16_t)chcfg(sg, l.out2.out_bits, sy, l.r_bits, l.r_exp);
+            }
+            o.sigdir = reinterpret_cast<const int16_t *>(put_raw(p, dir.data(), dir.size() * 2));
+            o.sigdir_bits = nb;
+        }
     }
     const s5fxp_dense_desc &dd = d->decoder;
     pack_mfma(p, [&](int k, int ch) { return dd.weight[(size_t)k * dd.M + ch]; }, dd.K, dd.M, f->dec);
@@ -457,7 +473,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         {
             CGateArgs a{};
             a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2.w;
-            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab;
+            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab; a.sigdir = fl.sigdir; a.sigdir_bits = fl.sigdir_bits;
             a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H;
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
@@ -470,7 +486,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
-            const size_t smem = 5 * (size_t)H * 4 + 32 + 4 * SIGTAB_WORDS + 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
+            const bool direct = s16 && fl.sigdir_bits > 0;
+            const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
+                                2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
@@ -484,6 +502,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
+                    } else if (direct) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true, true>, cg, smem, a, 768);
+                        else launch6g(k_cgate_p<2, 3, false, true, true>, cg, smem, a);
                     } else if (s16) {
                         if (big) launch6g(k_cgate_p<4, 6, false, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, false, true>, cg, smem, a);
