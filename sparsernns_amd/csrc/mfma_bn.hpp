@@ -63,95 +63,110 @@ __device__ __forceinline__ void block_allmax(float (&v)[NV], float (*red)[8])
 __device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float *ext, int H, LayerDyn *d, int32_t *status,
                                                     int32_t *status_exps, int xe)
 {
-    __shared__ float red[3][8];
-    __shared__ LayerDyn sd;
-    const int h = threadIdx.x;
+    // This runs on the critical path between two layers (nothing else is executing), so it is written for latency:
+    // every operand a channel needs is requested up front, each stage costs ONE barrier (its own reduction slots),
+    // and every thread derives the exponents itself from the reduced maxima instead of waiting for thread 0.
+    __shared__ float red[4][3][8];
+    const int h = threadIdx.x, lane = h & 63, wave = h >> 6, nw = (blockDim.x + 63) >> 6;
     const bool act = h < H;
     float e0 = 0.f, e1 = 0.f;
+    int32_t pm = 0, pi = 0, ps = 0, pb = 0;
     if (act) {
         e0 = __hip_atomic_load(ext + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         e1 = __hip_atomic_load(ext + H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pm = a.mm[h];
+        pi = a.isv[h];
+        if (a.scale) ps = a.scale[h];
+        if (a.bias) pb = a.bias[h];
     }
     const int32_t xlo = act ? (int32_t)(EXT_BIAS - e0) : 0, xhi = act ? (int32_t)(e1 - EXT_BIAS) : 0;
-    if (h == 0) sd = *d;
-    __syncthreads();
+    LayerDyn sd{};
+    auto allmax = [&](int stage, float (&v)[3], int nv) {
+        for (int i = 0; i < nv; ++i) {
+            float t = v[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+            if (lane == 0) red[stage][i][wave] = t;
+        }
+        __syncthreads();
+        for (int i = 0; i < nv; ++i) {
+            float t = red[stage][i][0];
+            for (int w = 1; w < nw; ++w) t = fmaxf(t, red[stage][i][w]);
+            v[i] = t;
+        }
+    };
+    // the BatchNorm chain of s5fxp_kernels.hpp bn_chain<>, operands in registers
+    auto c1 = [&](int32_t x) { return add_cb_apply(x, a.xb, pm, a.mb, sd.bn1, a.b1); };
+    auto c2 = [&](int32_t x) { return sat(asr(wmul(c1(x), pi), sd.rs2), a.b2); };
+    auto c3 = [&](int32_t x) {
+        const int32_t t = c2(x);
+        return a.scale ? sat(asr(wmul(t, ps), sd.rs3), a.b3) : t;
+    };
     // ---- stage 1: x + (-mean)        fxpmodel.py:892-897
     {
         float v[3] = {0.f, 0.f, 0.f};
         if (act) {
-            const float fm = tofloat(a.mm[h], a.me), f0 = tofloat(xlo, xe), f1 = tofloat(xhi, xe);
+            const float fm = tofloat(pm, a.me), f0 = tofloat(xlo, xe), f1 = tofloat(xhi, xe);
             v[0] = fmaxf(fabsf(__fadd_rn(f0, fm)), fabsf(__fadd_rn(f1, fm)));
             v[1] = fmaxf(fabsf(f0), fabsf(f1));
             v[2] = fabsf(fm);
         }
-        block_allmax<3>(v, red);
-        if (h == 0) {
-            uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
-            sd.mx[0] = m3[0]; sd.mx[1] = m3[1]; sd.mx[2] = m3[2];
-            sd.bn1 = finalize_add_cb(m3, xe, a.me, a.b1, status);
-            sd.bn_e = sd.bn1.eo;
-            status_exps[0] = sd.bn1.eo;
-        }
-        __syncthreads();
+        allmax(0, v, 3);
+        uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
+        sd.mx[0] = m3[0]; sd.mx[1] = m3[1]; sd.mx[2] = m3[2];
+        sd.bn1 = finalize_add_cb(m3, xe, a.me, a.b1, status);
+        sd.bn_e = sd.bn1.eo;
     }
     // ---- stage 2: * invsq_var        fxpmodel.py:902-907
     {
-        float v[1] = {0.f};
+        float v[3] = {0.f, 0.f, 0.f};
         if (act) {
-            const float fi = tofloat(a.isv[h], a.ie);
-            const float f0 = tofloat(bn_chain<1>(a, sd, xlo, h), sd.bn1.eo), f1 = tofloat(bn_chain<1>(a, sd, xhi, h), sd.bn1.eo);
+            const float fi = tofloat(pi, a.ie);
+            const float f0 = tofloat(c1(xlo), sd.bn1.eo), f1 = tofloat(c1(xhi), sd.bn1.eo);
             v[0] = fmaxf(fabsf(__fmul_rn(f0, fi)), fabsf(__fmul_rn(f1, fi)));
         }
-        block_allmax<1>(v, red);
-        if (h == 0) {
-            sd.mx[3] = __float_as_uint(v[0]);
-            finalize_mul_cb(sd.mx[3], sd.bn1.eo, a.ie, a.b2, sd.rs2, sd.e2, status);
-            sd.bn_e = sd.e2;
-            status_exps[1] = sd.e2;
-        }
-        __syncthreads();
+        allmax(1, v, 1);
+        sd.mx[3] = __float_as_uint(v[0]);
+        finalize_mul_cb(sd.mx[3], sd.bn1.eo, a.ie, a.b2, sd.rs2, sd.e2, status);
+        sd.bn_e = sd.e2;
     }
     // ---- stage 3: * scale            fxpmodel.py:915-920
     if (a.scale) {
-        float v[1] = {0.f};
+        float v[3] = {0.f, 0.f, 0.f};
         if (act) {
-            const float fs = tofloat(a.scale[h], a.se);
-            const float f0 = tofloat(bn_chain<2>(a, sd, xlo, h), sd.e2), f1 = tofloat(bn_chain<2>(a, sd, xhi, h), sd.e2);
+            const float fs = tofloat(ps, a.se);
+            const float f0 = tofloat(c2(xlo), sd.e2), f1 = tofloat(c2(xhi), sd.e2);
             v[0] = fmaxf(fabsf(__fmul_rn(f0, fs)), fabsf(__fmul_rn(f1, fs)));
         }
-        block_allmax<1>(v, red);
-        if (h == 0) {
-            sd.mx[4] = __float_as_uint(v[0]);
-            finalize_mul_cb(sd.mx[4], sd.e2, a.se, a.b3, sd.rs3, sd.e3, status);
-            sd.bn_e = sd.e3;
-            status_exps[2] = sd.e3;
-        }
-        __syncthreads();
+        allmax(2, v, 1);
+        sd.mx[4] = __float_as_uint(v[0]);
+        finalize_mul_cb(sd.mx[4], sd.e2, a.se, a.b3, sd.rs3, sd.e3, status);
+        sd.bn_e = sd.e3;
     }
     // ---- stage 4: + bias             fxpmodel.py:928-933
     if (a.bias) {
         const int e3 = a.scale ? sd.e3 : sd.e2;
         float v[3] = {0.f, 0.f, 0.f};
         if (act) {
-            const float fb = tofloat(a.bias[h], a.be);
-            const float f0 = tofloat(bn_chain<3>(a, sd, xlo, h), e3), f1 = tofloat(bn_chain<3>(a, sd, xhi, h), e3);
+            const float fb = tofloat(pb, a.be);
+            const float f0 = tofloat(c3(xlo), e3), f1 = tofloat(c3(xhi), e3);
             v[0] = fmaxf(fabsf(__fadd_rn(f0, fb)), fabsf(__fadd_rn(f1, fb)));
             v[1] = fmaxf(fabsf(f0), fabsf(f1));
             v[2] = fabsf(fb);
         }
-        block_allmax<3>(v, red);
-        if (h == 0) {
-            uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
-            sd.mx[5] = m3[0]; sd.mx[6] = m3[1]; sd.mx[7] = m3[2];
-            sd.bn4 = finalize_add_cb(m3, e3, a.be, a.b4, status);
-            sd.bn_e = sd.bn4.eo;
-            status_exps[3] = sd.bn4.eo;
-        }
-        __syncthreads();
+        allmax(3, v, 3);
+        uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
+        sd.mx[5] = m3[0]; sd.mx[6] = m3[1]; sd.mx[7] = m3[2];
+        sd.bn4 = finalize_add_cb(m3, e3, a.be, a.b4, status);
+        sd.bn_e = sd.bn4.eo;
     }
     if (h == 0) { // publish (redo and the residual maxima slots of *d are written later in the layer)
         d->bn1 = sd.bn1; d->rs2 = sd.rs2; d->e2 = sd.e2; d->rs3 = sd.rs3; d->e3 = sd.e3; d->bn4 = sd.bn4; d->bn_e = sd.bn_e;
         for (int i = 0; i < 8; ++i) d->mx[i] = sd.mx[i];
+        status_exps[0] = sd.bn1.eo;
+        status_exps[1] = sd.e2;
+        if (a.scale) status_exps[2] = sd.e3;
+        if (a.bias) status_exps[3] = sd.bn4.eo;
     }
 }
 

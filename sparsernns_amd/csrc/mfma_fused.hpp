@@ -139,7 +139,7 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
     const int cv_b = cv_b1 < cv_b2 ? cv_b1 : cv_b2;
     uint32_t xrange = 0;
     v2i16 pmax = {0, 0}, pmin = {0, 0}; // S16: running extremes of (re, im) as packed int16
-    float mx[3] = {0.f, 0.f, 0.f}; // |z*kz + s|, |z|, |s| as converted integers; scaled once at the end
+    float mx[3] = {0.f, 0.f, 0.f}; // [0]: |z*kz + s| as converted integers, scaled once at the end; [1], [2] stay 0
     const int ch0 = 32 * ct + 4 * h;
     __syncthreads();
 
@@ -299,9 +299,9 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
                         }
                         o[e] = z;
                         const float cz = (float)z, cs = (float)sv[e];
+                        // only max |z + skip| chooses the exponent (fxparray.py:421-425); the operands' own maxima
+                        // (slots 9, 10) merely size the reference's intermediate bit width and are not needed
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cz, kz, cs)));
-                        mx[1] = fmaxf(mx[1], fabsf(cz));
-                        mx[2] = fmaxf(mx[2], fabsf(cs));
                     }
                     *reinterpret_cast<v2i *>(a.z + n * H + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
                 }
