@@ -363,3 +363,17 @@ def test_audio_front_and_back_end_match_scipy():
     proj = (st * se).sum(-1, keepdims=True) * st / (st ** 2).sum(-1, keepdims=True)
     want = 10 * np.log10((proj ** 2).sum(-1) / (((se - proj) ** 2).sum(-1) + 1e-8) + 1e-8)
     assert np.allclose(audio.si_snr(torch.from_numpy(t), torch.from_numpy(e)).numpy(), want, atol=1e-4)
+
+
+def test_generated_scan_asm_is_up_to_date(tmp_path):
+    """sparsernns_amd/csrc/scan_quad_asm.inc is generated by tools/gen_scan_asm.py: the committed file must be what
+    the generator writes (so an edit of one without the other cannot ship)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_scan_asm", os.path.join(ROOT, "tools", "gen_scan_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    t32, _ = gen.emit("S5_SCAN_ASM", gen.Plan(False))
+    t16, _ = gen.emit("S5_SCAN16_ASM", gen.Plan(True))
+    have = open(os.path.join(ROOT, "sparsernns_amd", "csrc", "scan_quad_asm.inc")).read()
+    assert t32 in have and t16 in have and f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have
