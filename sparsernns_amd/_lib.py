@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64; libs5fxp.so links the same SONAME.  Whichever is loaded first is the HIP
+# runtime of the process, and the streams / device pointers handed to the C ABI are torch's: torch must come first,
+# or the library binds /opt/rocm's runtime and every launch fails with an invalid-handle error.
+import torch  # noqa: F401  (load order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # S5FXP_LIB: developer override to load an experimental build of the same library (tools/build_variant.sh)
 LIB_PATH = os.environ.get("S5FXP_LIB") or os.path.join(_HERE, "libs5fxp.so")

@@ -465,3 +465,16 @@ def test_pruned_model_op_by_op_goes_through_csr_and_force_csr_is_refused():
     assert np.array_equal(y.numpy(), ref)
     with pytest.raises(NotImplementedError):
         build_regression_model(md, qc, dims["n_layers"], engine_flags=_lib.MODEL_FORCE_CSR).engine()
+
+
+def test_smoke_entry_point_in_a_fresh_interpreter():
+    """The driver calls __graft_entry__.smoke() in its own process, where nothing has imported torch yet: the HIP
+    library must still end up on torch's HIP runtime (sparsernns_amd/_lib.py imports torch before loading it)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "[smoke] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
