@@ -1,0 +1,63 @@
+"""Randomised parity stress (GPU): fused forward vs the scalar C oracle over random shapes, scales and models.
+Not part of the test suite (minutes); run by hand:  python tools/stress_parity.py [n_cases] [seed]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+import __graft_entry__ as g
+g.build()
+from oracle import cref, fxp_oracle as O
+from sparsernns_amd import synth, _lib
+from sparsernns_amd.engine import InflightRunner
+from sparsernns_amd.fxparray import FxpArray
+from sparsernns_amd.fxpmodel import build_regression_model
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    dim = float(rng.choice([0.5, 0.5, 0.5, 1.0]))
+    cfg = dict(dim_scale=dim, seed=int(rng.integers(1, 10_000)), sparsity=float(rng.choice([0.0, 0.0, 0.9])),
+               calib_L=int(rng.choice([64, 128, 256])), state_headroom_bits=int(rng.choice([0, 1])))
+    if rng.random() < 0.25:
+        cfg.update(bn_scale_bias=True)
+    md, qc, dims = synth.make_model(**cfg)
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    B = int(rng.integers(1, 5))
+    L = 4 * int(rng.integers(1, 160 if dim == 0.5 else 60))
+    scale = float(rng.choice([0.3, 1.0, 1.0, 2.5, 6.0]))
+    runner = InflightRunner(eng, depth=int(rng.integers(1, 4)))
+    jobs = []
+    for j in range(3):
+        x = synth.make_input(B, L, dims["d_in"], seed=int(rng.integers(1, 10_000)), scale=scale)
+        fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+        xd = torch.from_numpy(fx.data).cuda()
+        y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+        try:
+            runner.submit(xd, fx.bits, fx.exp, y, B, L)
+        except Exception as e:  # ValueError / OverflowError are legitimate outcomes: the oracle must agree
+            jobs.append((fx, None, e)); continue
+        jobs.append((fx, y, None))
+    try:
+        runner.drain()
+        err = None
+    except Exception as e:
+        err = e
+    for j, (fx, y, e) in enumerate(jobs):
+        if y is None or err is not None:
+            print(f"case {case}.{j}: dim={dim} B={B} L={L} scale={scale} cfg={cfg} raised {e or err!r} (not compared)")
+            continue
+        ref, _, _, _ = cm.forward(fx.data, fx.bits, fx.exp)
+        same = np.array_equal(y.cpu().numpy(), ref)
+        if not same:
+            bad += 1
+            print(f"MISMATCH case {case}.{j}: dim={dim} B={B} L={L} scale={scale} cfg={cfg} "
+                  f"diff={np.count_nonzero(y.cpu().numpy() != ref)}")
+    st = int(eng.status[0].item())
+    print(f"case {case}: dim={dim} B={B} L={L} scale={scale} sparsity={cfg['sparsity']} fast={bool(_lib.lib.s5fxp_model_is_fast(eng._h))} "
+          f"status=0x{st:x} ok   [{time.time() - t0:.0f}s]", flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
