@@ -258,7 +258,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, w.dyn_bytes, st)))) return rc;
     // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
     // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
-    bool bn_ext = m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
+    // S5FXP_NO_BN_EXT=1 (tests): take the four-reduction path even when the extremes method applies
+    static const bool no_bn_ext = std::getenv("S5FXP_NO_BN_EXT") != nullptr;
+    bool bn_ext = !no_bn_ext && m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
     for (int li = 0; li < m->n_layers; ++li) {
         const s5fxp_norm_desc &n = m->layers[li].nd;
         auto ok = [](int bits, int e) { return bits <= 16 && e >= 0 && e <= 15; };

@@ -478,3 +478,33 @@ def test_smoke_entry_point_in_a_fresh_interpreter():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "[smoke] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_four_reduction_batchnorm_path_still_exact():
+    """The extremes method needs every BatchNorm operand within 16 bits and exponents in [0,15]; outside that the fast
+    path falls back to four tensor-wide reductions per layer (k_bn_reduce16 / k_bn_finalize / k_res_finalize /
+    k_resid16).  S5FXP_NO_BN_EXT=1 forces that path (read once per process: fresh interpreter)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, torch\n"
+        "from oracle import cref, fxp_oracle as O\n"
+        "from sparsernns_amd import synth\n"
+        "from sparsernns_amd.fxparray import FxpArray\n"
+        "from sparsernns_amd.fxpmodel import build_regression_model\n"
+        "md, qc, dims = synth.make_model(0.5, bn_scale_bias=True)\n"
+        "model = build_regression_model(md, qc, dims['n_layers'])\n"
+        "x = synth.make_input(2, 200, dims['d_in'], seed=4)\n"
+        "fx = O.from_fp(x, qc['encoder']['inp_bits'], qc['encoder']['inp_exp'], True, O.FLOOR)\n"
+        "y = model.engine().forward(FxpArray(fx.data, fx.bits, fx.exp))\n"
+        "ref, _, _, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)\n"
+        "assert np.array_equal(y.numpy(), ref)\n"
+        "y2 = model.engine().forward(FxpArray(fx.data, fx.bits, fx.exp), check_status=False)\n"
+        "assert np.array_equal(y2.numpy(), ref)\n"
+        "print('four-reduction path ok')\n")
+    env = dict(os.environ, S5FXP_NO_BN_EXT="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "four-reduction path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
