@@ -17,6 +17,15 @@
 
 namespace s5 {
 
+// one launch instead of two memsets at the head of a forward: the status words and the per-layer device state
+__global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) {
+        if (i < na) a[i] = 0;
+        else b[i - na] = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-channel extremes of an int16 (N,H) tensor as POSITIVE floats: ext[h] = 65536 - min_h, ext[H+h] =
 // 65536 + max_h (exact for 16-bit data).  Zero-initialised by a memset; atomicMax on the bit pattern;

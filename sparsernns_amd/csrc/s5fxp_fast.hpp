@@ -254,8 +254,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const bool big = (H == 192);
     const unsigned grid = mfma_grid(N);
     int rc;
-    if ((rc = hip_rc(hipMemsetAsync(status, 0, sizeof(int32_t) * S5FXP_STATUS_WORDS, st)))) return rc;
-    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, w.dyn_bytes, st)))) return rc;
+    hipLaunchKernelGGL(k_clear2, dim3(8), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
+                       (int)(w.dyn_bytes / 4));
     // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
     // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
     // S5FXP_NO_BN_EXT=1 (tests): take the four-reduction path even when the extremes method applies
