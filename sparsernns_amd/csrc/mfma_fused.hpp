@@ -88,14 +88,15 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // state fails the range check like any other state beyond the bound)
 // DIRECT: the sigmoid input xx = gq >> (out_exp - sig_x) has only out_bits - (out_exp - sig_x) <= 12 bits, so r is read
 // from a table over xx itself (no |xx|, segment index, remainder or sign logic at all)
-template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false>
+// FTP: frames per tile, 64 (two 32-frame halves, 2*NT waves) or 32 (NT waves: smaller workgroups, more of them per CU)
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
-__global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
+__global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
-    constexpr int P = 32 * KS, H = 32 * NT, FT = 64, NW = 2 * NT, NTHR = 64 * NW; // one wave per (half, column tile)
+    constexpr int P = 32 * KS, H = 32 * NT, FT = FTP, NW = (FT / 32) * NT, NTHR = 64 * NW; // one wave per (half, column tile)
     constexpr int KPS = 2 * P + 16, KPX = H + 16;
     constexpr int NU = 1, SUBSTEP = 0;   // units per wave
-    constexpr int ITEMS = 16 * P, ROUNDS = (ITEMS + NTHR - 1) / NTHR;
+    constexpr int ITEMS = (FT / 4) * P, ROUNDS = (ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
     int32_t *sigt = lutp + 8; // SIGTAB_WORDS, or the direct table (int16, SIGDIR_BYTES)
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(128 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         int64_t b0;
         int t0, nvalid;
-        tile_of(tile, sr, b0, t0, nvalid);
+        tile_of<FT>(tile, sr, b0, t0, nvalid);
         const int64_t n0 = b0 * a.L + t0;
         // ---- u and skip of this wave's units: requested first, consumed in the epilogues
         v2i uq[NU][4], sq[NU][4];

@@ -36,13 +36,14 @@ __device__ __forceinline__ void planes8_from_i32(const int32_t (&v)[8], v2i &hi,
 struct StepRange {
     int32_t t_lo, t_len; // multiples of 4 (t_lo: of 64)
 };
+template <int FT = 64>
 __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64_t &b, int &t, int &nvalid)
 {
-    const int tps = (sr.t_len + 63) >> 6;
+    const int tps = (sr.t_len + FT - 1) / FT;
     b = tile / tps;
-    const int tt = (int)(tile - b * tps) << 6;
+    const int tt = (int)(tile - b * tps) * FT;
     t = sr.t_lo + tt;
-    nvalid = sr.t_len - tt < 64 ? sr.t_len - tt : 64;
+    nvalid = sr.t_len - tt < FT ? sr.t_len - tt : FT;
 }
 
 // S16: the stream holds int16 (the host has checked that every value fits: Bu bits minus the shift to the state
