@@ -52,7 +52,9 @@ def main() -> None:
     ap.add_argument("--dim-scale", type=float, default=0.5)
     ap.add_argument("--sparsity", type=float, default=0.0)
     ap.add_argument("--quantization", default="w8a16")
-    ap.add_argument("--state-headroom-bits", type=int, default=1)
+    ap.add_argument("--state-headroom-bits", type=int, default=None,
+                    help="extra integer bits of the SSM state in the synthetic qconfig (default 1; 2 for pruned models, whose\n"
+                         "fixed-point states drift further from the float calibration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32, help="sequences per pass of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
@@ -96,6 +98,8 @@ def main() -> None:
     dev = torch.device("cuda", torch.cuda.current_device())
 
     B, L = args.batch, args.seq_len
+    if args.state_headroom_bits is None:
+        args.state_headroom_bits = 2 if args.sparsity > 0 else 1
     # one extra integer bit for the (never clipped) SSM state: see synth.make_model(state_headroom_bits)
     md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity,
                                     calib_L=1024, state_headroom_bits=args.state_headroom_bits)
