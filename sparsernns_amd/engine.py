@@ -55,6 +55,9 @@ class Engine:
         # a lane = the per-forward mutable state (status words + workspace); forwards on different lanes may be
         # in flight at the same time on different streams (InflightRunner).  Lane 0 is the default.
         self._status = {0: torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)}
+        # optimistic forwards that came back with ST_REDO; after two, forward() / InflightRunner stop trying the fast
+        # recurrence for this model (its states do not fit) and enqueue the exact kernels directly
+        self.redo_seen = 0
         self._wsl: Dict[int, tuple] = {}
         self._cb_keep = None
 
@@ -214,9 +217,11 @@ class Engine:
         else:
             # the status words are read anyway: run optimistically and repeat with the exact kernels if a state
             # left the fast recurrence's range (never with a multi-rank hook: ranks must enqueue the same work)
-            self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=0 if allreduce else _lib.FWD_DEFER_REDO)
+            first = 0 if allreduce else (_lib.FWD_EXACT if self.redo_seen >= 2 else _lib.FWD_DEFER_REDO)
+            self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=first)
             st = self.check_status()
             if st[0] & _lib.ST_REDO:
+                self.redo_seen += 1
                 self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=_lib.FWD_EXACT)
                 self.check_status()
         out = FxpArray(y, self.out_bits, self.out_exp, True)
@@ -253,8 +258,9 @@ class InflightRunner:
             self._finish(lane)
         s = self.streams[lane]
         s.wait_stream(torch.cuda.current_stream(self.engine.device))
+        flags = _lib.FWD_EXACT if self.engine.redo_seen >= 2 else _lib.FWD_DEFER_REDO
         with torch.cuda.stream(s):
-            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_DEFER_REDO, lane=lane, scan_events=scan_events)
+            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=flags, lane=lane, scan_events=scan_events)
         self._pending[lane] = (x, x_bits, x_exp, y, B, L)
         return lane
 
@@ -267,6 +273,7 @@ class InflightRunner:
         s.synchronize()
         st = self.engine.check_status(lane)
         if st[0] & _lib.ST_REDO:
+            self.engine.redo_seen += 1
             x, x_bits, x_exp, y, B, L = job
             with torch.cuda.stream(s):
                 self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_EXACT, lane=lane)
