@@ -35,6 +35,8 @@ struct CGateArgs {
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
     int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
     const int32_t *sigtab; // [2][7 << sig_x]: gate operand r for a non-positive / positive sigmoid input (k_cgate_p)
+    const int32_t *run_if; // WIDE (exact re-run): do the work only when *run_if != 0 (nullptr: always)
+    int32_t mx_slot;       // first of the three LayerDyn::mx slots that receive the maxima (8; 11 for the re-run)
     const int16_t *sigdir; // DIRECT: [1 << sigdir_bits] gate operand r for every value of (gq >> (out_exp - sig_x))
     int32_t sigdir_bits;
 };
@@ -89,7 +91,12 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // DIRECT: the sigmoid input xx = gq >> (out_exp - sig_x) has only out_bits - (out_exp - sig_x) <= 12 bits, so r is read
 // from a table over xx itself (no |xx|, segment index, remainder or sign logic at all)
 // FTP: frames per tile, 64 (two 32-frame halves, 2*NT waves) or 32 (NT waves: smaller workgroups, more of them per CU)
-template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64>
+// WIDE: the exact variant for states of any width (the re-run behind the range check): int32 states are split into
+// FOUR byte planes, a = b3*2^24 + (b2'+128)*2^16 + (b1'+128)*2^8 + (b0'+128) with b3 signed and b' = byte ^ 0x80, so
+// sum a*w = Horner over four MFMA passes with the same per-channel constant 128*sum(w) added at each of the three shifts
+// -- all modulo 2^32, which is the reference's int32 matmul (fxparray.py:662).  No range check, complex ReLU through
+// float32 exactly as the reference does it (fxp_prims.hpp crelu).
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
@@ -101,12 +108,15 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
     int32_t *sigt = lutp + 8; // SIGTAB_WORDS, or the direct table (int16, SIGDIR_BYTES)
     const int16_t *sigd = reinterpret_cast<const int16_t *>(sigt);
-    int8_t *Sh = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? SIGDIR_BYTES : 4 * SIGTAB_WORDS), *Sl = Sh + FT * KPS, *Xh = Sl + FT * KPS, *Xl = Xh + FT * KPX;
+    constexpr int NPL = WIDE ? 4 : 2; // byte planes of the state operand; plane NPL-1 is the signed top byte
+    int8_t *Sbase = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? SIGDIR_BYTES : 4 * SIGTAB_WORDS);
+    int8_t *Sl = Sbase, *Sh = Sbase + (NPL - 1) * FT * KPS, *Xh = Sbase + NPL * FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
     const StepRange sr{a.t_lo, a.t_len};
     const int64_t tiles = (a.N / a.L) * ((sr.t_len + FT - 1) / FT);
+    if (WIDE && a.run_if && *a.run_if == 0) return;
 
     // weights of this wave's 32 channels (A operand rows), all k-steps, in registers
     v4i wre[KS], wim[KS], wo2[NT];
@@ -171,6 +181,29 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                 int o = 4 * grp;
                 if (o >= nvalid) o = nvalid - 4; // partial tile: re-read the last block (results unused)
                 int32_t w[4];
+                if (WIDE) {
+                    const int32_t *src = a.xs + native_word(b0, t0 + o, p, 0, a.TB, P);
+                    const v4i cre = *reinterpret_cast<const v4i *>(src), cim = *reinterpret_cast<const v4i *>(src + 4);
+                    int32_t xr[4] = {cre[0], cre[1], cre[2], cre[3]}, xi[4] = {cim[0], cim[1], cim[2], cim[3]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) crelu(xr[j], xi[j]);
+                    quad_transpose(xr, l);
+                    quad_transpose(xi, l);
+                    // this lane = frame 4*grp + (l&3); xr[m], xi[m] = state (p & ~3) + m: four byte planes each
+                    const int row = (4 * grp + (l & 3)) * KPS + (p & ~3);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int32_t(&v)[4] = c ? xi : xr;
+                        const unsigned t01 = perm((unsigned)v[1], (unsigned)v[0], 0x05010400u), u01 = perm((unsigned)v[1], (unsigned)v[0], 0x07030602u);
+                        const unsigned t23 = perm((unsigned)v[3], (unsigned)v[2], 0x05010400u), u23 = perm((unsigned)v[3], (unsigned)v[2], 0x07030602u);
+                        int8_t *dst = Sbase + row + c * P;
+                        *reinterpret_cast<int32_t *>(dst) = (int32_t)(perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+                        *reinterpret_cast<int32_t *>(dst + FT * KPS) = (int32_t)(perm(t23, t01, 0x07060302u) ^ 0x80808080u);
+                        *reinterpret_cast<int32_t *>(dst + 2 * FT * KPS) = (int32_t)(perm(u23, u01, 0x05040100u) ^ 0x80808080u);
+                        *reinterpret_cast<int32_t *>(dst + 3 * FT * KPS) = (int32_t)perm(u23, u01, 0x07060302u);
+                    }
+                    continue;
+                }
                 if (S16) {
                     // 16 bytes: re of steps 0..3, then im of steps 0..3, as int16; w[j] = re_j | im_j << 16 by two perms
                     const v4i q4 = *reinterpret_cast<const v4i *>(reinterpret_cast<const int16_t *>(a.xs) + native_word(b0, t0 + o, p, 0, a.TB, P));
@@ -217,10 +250,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
         for (int u = 0; u < NU; ++u) {
             const int sub = sub0 + u * SUBSTEP;
             const int64_t n = n0 + 32 * sub + r;
-            const int8_t *rowh = Sh + (32 * sub + r) * KPS + 16 * h, *rowl = Sl + (32 * sub + r) * KPS + 16 * h;
+            const int8_t *row0 = Sbase + (32 * sub + r) * KPS + 16 * h;
             v16i are, aim;
-            mfma_planes<KS>(are, wre, rowh, rowl, csr + ch0);
-            mfma_planes<KS>(aim, wim, rowh + P, rowl + P, csi + ch0);
+            mfma_nplanes<KS, NPL>(are, wre, row0, FT * KPS, csr + ch0);
+            mfma_nplanes<KS, NPL>(aim, wim, row0 + P, FT * KPS, csi + ch0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4i Dv = *reinterpret_cast<const v4i *>(Dl + ch0 + 8 * g);
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
     if (threadIdx.x < 3) {
         float x = red[threadIdx.x * 16];
         for (int w = 1; w < NW; ++w) x = fmaxf(x, red[threadIdx.x * 16 + w]);
-        atomicMax(a.dynw->mx + 8 + threadIdx.x, __float_as_uint(x));
+        atomicMax(a.dynw->mx + a.mx_slot + threadIdx.x, __float_as_uint(x));
     }
 }
 

@@ -217,6 +217,31 @@ __device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], c
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(rowl + 32 * ks), acc, 0, 0, 0);
 }
 
+// the same for NPL byte planes [plane][frame][k] (plane NPL-1 = signed top byte), Horner from the top: the constant
+// 128*sum(w) enters at every shift, so after NPL-1 shifts it has the weight 2^(8(NPL-2)) + ... + 2^8 + 1 that the
+// +128 offsets of the lower planes need
+template <int KSTEPS, int NPL>
+__device__ __forceinline__ void mfma_nplanes(v16i &acc, const v4i (&w)[KSTEPS], const int8_t *row0, int plane_stride,
+                                             const int32_t *cs)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+    for (int pl = NPL - 1; pl >= 0; --pl) {
+        if (pl != NPL - 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i c = *reinterpret_cast<const v4i *>(cs + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] = wadd(wshl(acc[4 * g + e], 8), c[e]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(row0 + pl * plane_stride + 32 * ks), acc, 0, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Encoder, phase-split: x int32 (N,K) -> relu(dense) int16 (N,H).  fxpmodel.py:331-366, 1263-1266.
 // Six waves, 64-frame tiles.  Phase A: a wave reads whole rows (64 lanes x 4 consecutive k, 1 KB contiguous)

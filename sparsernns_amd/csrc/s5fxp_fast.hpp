@@ -475,7 +475,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         {
             CGateArgs a{};
             a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2.w;
-            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab; a.sigdir = fl.sigdir; a.sigdir_bits = fl.sigdir_bits;
+            a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab; a.sigdir = fl.sigdir; a.sigdir_bits = fl.sigdir_bits; a.mx_slot = 8;
             a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H;
             a.rs_re = s.x_re_exp + s.C_re_exp - s.y_exp; a.rs_im = s.x_im_exp + s.C_im_exp - s.y_exp;
@@ -523,18 +523,21 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     sl.run_if = &d->redo;
                     hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
                 }
-                CprojArgs g{};
-                g.bn = bn; g.x = h; g.xs = I32(w.xs); g.w_re = l.c_re_t; g.w_im = l.c_im_t; g.D = l.D;
-                g.x1 = I16(w.x1); g.tr_ys = tr ? tr->ys : nullptr; g.N = N; g.L = L; g.TB = w.TB; g.H = H; g.P = P;
-                g.mw = mw_for(H); g.rs_re = a.rs_re; g.rs_im = a.rs_im; g.rs_d = a.rs_d; g.y_bits = s.y_bits;
-                g.xmax = xmax; g.dynw = d; g.status = status;
-                const unsigned tiles = (unsigned)((N + TN - 1) / TN);
-                S5_DISPATCH_MW_C(g.mw, false, 1, int16_t, tiles, st, g);
-                ga.run_if = &d->redo; // the re-run's gate kernel: maxima in slots 11..13
-                ga.mx_slot = 11;
-                const size_t smem2 = (size_t)ga.w.Np * ga.w.Kp + 2 * (size_t)ga.w.Np * 4 + 32;
-                if (big) launch_smem(k_out2gate_mfma<6, 6>, grid, smem2, st, ga);
-                else launch_smem(k_out2gate_mfma<3, 3>, grid, smem2, st, ga);
+                // the exact gate kernel: four byte planes of the int32 states, no range assumption; its maxima go to
+                // slots 11..13, which the residual pass picks when `redo` is set
+                CGateArgs e = a;
+                e.run_if = &d->redo; e.mx_slot = 11; e.t_lo = 0; e.t_len = L; e.bad_bits = 0;
+                const size_t smem_w = 5 * (size_t)H * 4 + 32 + 4 * (size_t)SIGTAB_WORDS + 4 * 64 * (size_t)(2 * P + 16) +
+                                      2 * 64 * (size_t)(H + 16) + 192;
+                const int64_t tlw = (int64_t)B * ((L + 63) / 64), perw = (tlw + 511) / 512;
+                const unsigned cgw = (unsigned)((tlw + perw - 1) / perw);
+                if (tr) {
+                    if (big) launch6g(k_cgate_p<4, 6, true, false, false, 64, true>, cgw, smem_w, e, 768);
+                    else launch6g(k_cgate_p<2, 3, true, false, false, 64, true>, cgw, smem_w, e);
+                } else {
+                    if (big) launch6g(k_cgate_p<4, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
+                    else launch6g(k_cgate_p<2, 3, false, false, false, 64, true>, cgw, smem_w, e);
+                }
             }
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
