@@ -174,103 +174,6 @@ struct GateMArgs {
     int32_t mx_slot;       // first of the three LayerDyn::mx slots that receive the maxima
 };
 
-template <int KS, int NT>
-__global__ __launch_bounds__(256, 2) void k_out2gate_mfma(GateMArgs a)
-{
-    if (a.run_if && *a.run_if == 0) return;
-    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-    const int wbytes = a.w.Np * a.w.Kp;
-    int32_t *cs = reinterpret_cast<int32_t *>(smem + wbytes), *be = cs + a.w.Np, *lut = be + a.w.Np;
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
-    const int64_t tiles = (a.N + 31) / 32;
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    // Every global load of a tile -- MFMA fragments and the epilogue's x1 / skip operands -- is issued in one
-    // go (for the first tile even before the weights are staged), so a tile costs one round of memory latency.
-    v4i raw[KS][2];
-    v2i xq[NT][4], sq[NT][4];
-    auto fetch = [&](int64_t tl) {
-        int64_t n = tl * 32 + r;
-        n = n < a.N ? n : a.N - 1;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            raw[ks][0] = *reinterpret_cast<const v4i *>(a.x1 + n * a.H + 32 * ks + 16 * h);
-            raw[ks][1] = *reinterpret_cast<const v4i *>(a.x1 + n * a.H + 32 * ks + 16 * h + 8);
-        }
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                xq[ct][g] = *reinterpret_cast<const v2i *>(a.x1 + n * a.H + 32 * ct + 8 * g + 4 * h);
-                sq[ct][g] = *reinterpret_cast<const v2i *>(a.skip + n * a.H + 32 * ct + 8 * g + 4 * h);
-            }
-    };
-    if (tile < tiles) fetch(tile);
-    if (threadIdx.x < 8) lut[threadIdx.x] = a.lut[threadIdx.x];
-    stage_lds(smem, a.w.wt, wbytes);
-    stage_lds(cs, a.w.cs128, a.w.Np * 4);
-    stage_lds(be, a.bias_eff, a.w.Np * 4);
-    __syncthreads();
-    const int skip_e = a.skip_e.get();
-    float mx[3] = {0.f, 0.f, 0.f};
-    for (; tile < tiles; tile += stride) {
-        const int64_t n = tile * 32 + r;
-        v4i hi[KS], lo[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (a.conv) {
-                int32_t v[16];
-                unpack_i16(raw[ks][0], raw[ks][1], v);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = chcfg(v[j], a.y_bits, a.y_exp, a.inp_bits, a.inp_exp);
-                planes_from_i32(v, hi[ks], lo[ks]);
-            } else {
-                planes_from_i16(raw[ks][0], raw[ks][1], hi[ks], lo[ks]);
-            }
-        }
-        S5_FENCE();
-        v16i acc[NT];
-        mfma_2plane<KS, NT>(acc, smem, a.w.Kp, cs, 0, hi, lo);
-        S5_FENCE();
-        if (n < a.N) {
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = acc_channel(ct, g);
-                    if (ch < a.H) {
-                        const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
-                        int32_t xv[4], sv[4], o[4];
-                        unpack4_i16(xq[ct][g], xv);
-                        unpack4_i16(sq[ct][g], sv);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            int32_t gq = sat(asr(acc[ct][4 * g + e], a.rs), a.out_bits);
-                            gq = sat(wadd(gq, bv[e]), a.out_bits);
-                            if (a.tr_out2) a.tr_out2[n * a.H + ch + e] = gq;
-                            const int32_t s = sigmoid_lut(gq, a.out_bits, a.out_exp, a.sig_x, a.sig_y, lut);
-                            if (a.tr_sig) a.tr_sig[n * a.H + ch + e] = s;
-                            const int32_t lq = chcfg(xv[e], a.y_bits, a.y_exp, a.l_bits, a.l_exp);
-                            const int32_t rq = chcfg(s, a.out_bits, a.sig_y, a.r_bits, a.r_exp);
-                            const int32_t z = sat(asr(wmul(lq, rq), a.rs_gate), a.res_bits);
-                            if (a.tr_z) a.tr_z[n * a.H + ch + e] = z;
-                            o[e] = z;
-                            const float fz = tofloat(z, a.res_exp), fs = tofloat(sv[e], skip_e);
-                            mx[0] = fmaxf(mx[0], fabsf(__fadd_rn(fz, fs)));
-                            mx[1] = fmaxf(mx[1], fabsf(fz));
-                            mx[2] = fmaxf(mx[2], fabsf(fs));
-                        }
-                        *reinterpret_cast<v2i *>(a.z + n * a.H + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
-                    }
-                }
-                S5_FENCE();
-            }
-        }
-        if (tile + stride < tiles) fetch(tile + stride);
-    }
-    block_max_atomic<3>(mx, a.dynw->mx + a.mx_slot);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Decoder: int16 (N,H) with a device-chosen exponent -> int32 (N,M).  fxpmodel.py:1437, 331-366.
 // CG column groups of NT tiles are processed one after the other from the same activation fragments.
