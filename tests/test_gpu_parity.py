@@ -508,3 +508,33 @@ def test_four_reduction_batchnorm_path_still_exact():
     env = dict(os.environ, S5FXP_NO_BN_EXT="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "four-reduction path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_forward_is_capturable_in_a_hip_graph():
+    """One forward is a fixed sequence of launches on the caller's stream (no allocation, no host round trip, no
+    memset in the optimistic mode): it can be captured once and replayed."""
+    import torch
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5, calib_L=256, state_headroom_bits=1))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    B, L = 3, 320
+    fx = _input(qc, dims, B, L, seed=31)
+    xd = torch.from_numpy(fx.data).cuda()
+    y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eng.enqueue(xd, fx.bits, fx.exp, y, B, L, flags=_lib.FWD_DEFER_REDO)  # allocates the workspace, sets attributes
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            eng.enqueue(xd, fx.bits, fx.exp, y, B, L, flags=_lib.FWD_DEFER_REDO)
+    ref, _, _, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
+    for _ in range(2):
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy(), ref)
+        assert not int(eng.status[0].item()) & _lib.ST_REDO
