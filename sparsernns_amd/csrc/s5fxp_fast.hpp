@@ -450,8 +450,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
             if (s16 && xmax > 32766) xmax = 32766; // a saturated int16 state must fail the check
         } else {
-            sl.run_if = nullptr;
-            hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+            // states of any width: the exact 32-bit chain in the same quad layout
+            ScanQuadArgs q{};
+            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = nullptr;
+            hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
         }
         if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], sst)))) return rc;
         // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
@@ -520,8 +523,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // S5FXP_FWD_DEFER_REDO the caller repeats the forward instead (S5FXP_ST_REDO)
             if (!defer) {
                 if (quad) {
-                    sl.run_if = &d->redo;
-                    hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
+                    ScanQuadArgs q{};
+                    q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+                    q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = &d->redo;
+                    hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
                 }
                 // the exact gate kernel: four byte planes of the int32 states, no range assumption; its maxima go to
                 // slots 11..13, which the residual pass picks when `redo` is set

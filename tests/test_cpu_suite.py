@@ -375,5 +375,6 @@ def test_generated_scan_asm_is_up_to_date(tmp_path):
     spec.loader.exec_module(gen)
     t32, _ = gen.emit("S5_SCAN_ASM", gen.Plan(False))
     t16, _ = gen.emit("S5_SCAN16_ASM", gen.Plan(True))
+    t32w, _ = gen.emit("S5_SCAN32W_ASM", gen.Plan(False, wide=True))
     have = open(os.path.join(ROOT, "sparsernns_amd", "csrc", "scan_quad_asm.inc")).read()
-    assert t32 in have and t16 in have and f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have
+    assert t32 in have and t16 in have and t32w in have and f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have

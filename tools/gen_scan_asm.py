@@ -11,6 +11,8 @@ chain; the fillers make the memory traffic free).
 
 Two bodies:
   S5_SCAN_ASM_BODY    int32 streams: 16-byte items (4 steps of one component) in and out
+  S5_SCAN32W_ASM_BODY the exact chain for states of any width (the re-run behind the range check): 32-bit
+                      v_mul_lo_u32, arithmetic shift, conditional negation, v_add3; int32 streams
   S5_SCAN16_ASM_BODY  int16 streams: 8-byte items; the input word is picked by the SDWA source select
                       (sext WORD_0 / WORD_1) at no cost, the four new states of a block are packed by two
                       v_cvt_pk_i16_i32 (saturating: a state beyond 16 bits comes out as +-32767/8, which the
@@ -27,8 +29,9 @@ PERM = ("[2,3,0,1]", "[3,2,1,0]")  # phase A (even steps), phase B (odd steps)
 
 
 class Plan:
-    def __init__(self, s16: bool):
+    def __init__(self, s16: bool, wide: bool = False):
         self.s16 = s16
+        self.wide = wide                        # exact 32-bit chain (any state width)
         self.W = 2 if s16 else 4               # ring registers per block
         self.R0 = 32
         self.OA = self.R0 + self.W * DEPTH      # output tuple A (4 regs)
@@ -44,6 +47,18 @@ class Plan:
 
 
 def step(P, c, k, xprev, i, j, out_reg, perm, f1, f2):
+    if P.wide:
+        # (A*x wraps like the reference's int32 product) >> e, negated on the lane that owes -floor(.): -(a >> e) ==
+        # ((a >> e) ^ -1) + 1, so one xor with a per-lane mask and a three-operand add that brings Bu and the +1
+        ph = "a" if j % 2 == 0 else "b"
+        return [
+            f"v_mul_lo_u32 v{P.TMP}, {c}, v{xprev}",
+            f"v_ashrrev_i32 v{P.TMP}, %[s{ph}], v{P.TMP}",
+            f"v_xor_b32 v{P.TMP}, %[m{ph}], v{P.TMP}",
+            f"v_add3_u32 v{P.TMP}, v{P.TMP}, v{P.R0 + 4 * i + j}, %[o{ph}]",
+            f1, f2,
+            f"v_add_u32_dpp v{out_reg}, v{P.TMP}, v{P.TMP} quad_perm:{perm} row_mask:0xf bank_mask:0xf",
+        ]
     if P.s16:
         src1, sel = f"sext(v{P.R0 + 2 * i + (j >> 1)})", f"WORD_{j & 1}"
     else:
@@ -144,15 +159,18 @@ def emit(name, P):
 def main():
     t32, n32 = emit("S5_SCAN_ASM", Plan(False))
     t16, n16 = emit("S5_SCAN16_ASM", Plan(True))
+    t32w, n32w = emit("S5_SCAN32W_ASM", Plan(False, wide=True))
     out = f"""// GENERATED by tools/gen_scan_asm.py -- do not edit.  DEPTH = {DEPTH}.
 // Operands: [ca] [cb] [ka] [kb] [voff] [x0] VGPR inputs; [rin] [rout] 128-bit SGPR buffer descriptors;
 // [stride] SGPR bytes per time block; [sld] [sst] [cnt] SGPR read-write (load / store offsets, iterations).
+// S5_SCAN32W_ASM_BODY (exact 32-bit chain): [ca] [cb] are the plain multipliers, plus [sa] [sb] shifts, [ma] [mb] negation
+// masks (0 / -1) and [oa] [ob] = mask & 1, all VGPR inputs; [ka] [kb] unused.
 #define S5_SCAN_ASM_DEPTH {DEPTH}
-{t32}{t16}"""
+{t32}{t16}{t32w}"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparsernns_amd", "csrc", "scan_quad_asm.inc")
     with open(path, "w") as f:
         f.write(out)
-    print("wrote", os.path.normpath(path), n32, "+", n16, "instructions")
+    print("wrote", os.path.normpath(path), n32, "+", n16, "+", n32w, "instructions")
 
 
 if __name__ == "__main__":
