@@ -13,6 +13,9 @@ from sparsernns_amd.fxparray import FxpArray
 from sparsernns_amd.fxpmodel import build_regression_model
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+# third argument: comma-separated input scales to draw from (large ones push the states out of the 16-bit fast range
+# and exercise the exact kernels)
+SCALES = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0.3, 1.0, 1.0, 2.5, 6.0]
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 t0 = time.time()
@@ -28,7 +31,7 @@ for case in range(n_cases):
     cm = cref.CModel(model.export())
     B = int(rng.integers(1, 5))
     L = 4 * int(rng.integers(1, 160 if dim == 0.5 else 60))
-    scale = float(rng.choice([0.3, 1.0, 1.0, 2.5, 6.0]))
+    scale = float(rng.choice(SCALES))
     runner = InflightRunner(eng, depth=int(rng.integers(1, 4)))
     jobs = []
     for j in range(3):
