@@ -424,10 +424,6 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             }
         }
         // ---- recurrence
-        ScanArgs sl{};
-        sl.bu_re = I32(w.bq); sl.a_re = l.a_re; sl.a_im = l.a_im; sl.out_re = I32(w.xs);
-        sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
-        const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = 32767; // the C projection's 16-bit planes
         const bool piped = quad && n_chunks > 1;
         hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
