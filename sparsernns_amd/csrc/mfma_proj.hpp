@@ -8,16 +8,12 @@
 // a per-column constant.  The accumulator is int32 and wraps (probed: tools/probe_mfma_i8.hip), and
 // |sum| < 2^31 whenever K*2^15*2^7 < 2^31, so the result equals fxparray.py:662 bit for bit.
 //
-// Orientation: D^T = W^T (A operand, rows = output channels) x X^T (B operand, columns = frames).
-// A lane then owns ONE frame and, per 32-channel tile, four groups of four consecutive channels
-// (rows (i&3) + 8*(i>>2) + 4*(lane>>5)), so every fused epilogue runs per frame with 8-byte int16
-// stores.  Activation fragments come straight from global memory (16 consecutive k per lane);
-// the small weight matrix and the per-channel constants are staged once per workgroup in LDS
-// (weights as [channel][k] with a row stride whose 16-byte count is odd: conflict-free ds_read_b128).
-//
-// Activations between these kernels are int16 (N,H); the recurrence streams stay int32 (scan_quad.hpp).
-// Register discipline: fragment loads run as explicit 2-deep pipelines and the unrolled epilogues are
-// fenced with sched_barrier, otherwise the compiler hoists every load of the unrolled body and spills.
+// This header holds what the MFMA kernels share: the packed-weight descriptor (MfmaW: [channel][k] int8 rows, row
+// stride with an odd count of 16-byte slots, 128*colsum per channel), byte-plane and int16 pack/unpack helpers, the
+// argument blocks of the encoder / decoder, and the element-wise kernels of the four-reduction BatchNorm path
+// (k_bn_reduce16, k_resid16).  The kernels themselves are the phase-split ones in proj_p.hpp (encoder, B projection,
+// decoder) and mfma_fused.hpp (C projection + gate): see proj_p.hpp for the design.
+// Activations between kernels are int16 (N,H); the recurrence streams are int32 or int16 (scan_quad.hpp).
 #pragma once
 #include "s5fxp_kernels.hpp"
 
@@ -33,44 +29,7 @@ struct MfmaW {
     int32_t Kp, Np;       // row stride in bytes; padded channel count (multiple of 32)
 };
 
-#define S5_FENCE() __builtin_amdgcn_sched_barrier(0)
-
 __device__ __forceinline__ unsigned perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
-
-// 16 values held in int32 registers -> byte planes (4 packed registers each)
-__device__ __forceinline__ void planes_from_i32(const int32_t (&v)[16], v4i &hi, v4i &lo)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned p01 = perm((unsigned)v[4 * j + 1], (unsigned)v[4 * j], 0x05010400u);     // a0l a1l a0h a1h
-        const unsigned p23 = perm((unsigned)v[4 * j + 3], (unsigned)v[4 * j + 2], 0x05010400u); // a2l a3l a2h a3h
-        lo[j] = (int)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
-        hi[j] = (int)perm(p23, p01, 0x07060302u);
-    }
-}
-
-// 16 int16 values packed two per register (as they lie in memory) -> byte planes
-__device__ __forceinline__ void planes_from_i16(const v4i &w0, const v4i &w1, v4i &hi, v4i &lo)
-{
-    const unsigned r[8] = {(unsigned)w0[0], (unsigned)w0[1], (unsigned)w0[2], (unsigned)w0[3],
-                           (unsigned)w1[0], (unsigned)w1[1], (unsigned)w1[2], (unsigned)w1[3]};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lo[j] = (int)(perm(r[2 * j + 1], r[2 * j], 0x06040200u) ^ 0x80808080u);
-        hi[j] = (int)perm(r[2 * j + 1], r[2 * j], 0x07050301u);
-    }
-}
-
-__device__ __forceinline__ void unpack_i16(const v4i &w0, const v4i &w1, int32_t (&v)[16])
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[2 * j] = (int32_t)(int16_t)(w0[j] & 0xffff);
-        v[2 * j + 1] = w0[j] >> 16;
-        v[8 + 2 * j] = (int32_t)(int16_t)(w1[j] & 0xffff);
-        v[8 + 2 * j + 1] = w1[j] >> 16;
-    }
-}
 
 __device__ __forceinline__ v2i pack4_i16(int32_t a, int32_t b, int32_t c, int32_t d)
 {
@@ -87,53 +46,6 @@ __device__ __forceinline__ void unpack4_i16(const v2i &w, int32_t (&v)[4])
     v[2] = (int32_t)(int16_t)(w[1] & 0xffff);
     v[3] = w[1] >> 16;
 }
-
-// cooperative global -> LDS copy (bytes % 16 == 0, both 16-byte aligned)
-__device__ __forceinline__ void stage_lds(void *dst, const void *src, int bytes)
-{
-    for (int o = threadIdx.x * 16; o < bytes; o += blockDim.x * 16)
-        *reinterpret_cast<v4i *>(reinterpret_cast<int8_t *>(dst) + o) =
-            *reinterpret_cast<const v4i *>(reinterpret_cast<const int8_t *>(src) + o);
-}
-
-// acc[ct] = sum_k W[ch][k] * a[k][frame] + cs[ch] for NT column tiles starting at tile ct0.
-// cs (LDS, Np ints) is the per-channel constant 128*colsum; it rides on the shift between the passes.
-template <int KS, int NT>
-__device__ __forceinline__ void mfma_2plane(v16i (&acc)[NT], const int8_t *Wl, int Kp, const int32_t *cs, int ct0,
-                                            const v4i (&hi)[KS], const v4i (&lo)[KS])
-{
-    const int l = threadIdx.x & 63, r = l & 31, h = l >> 5;
-    const int8_t *wrow = Wl + (size_t)(32 * ct0 + r) * Kp + 16 * h;
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[ct][i] = 0;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const v4i w = *reinterpret_cast<const v4i *>(wrow + (size_t)32 * ct * Kp + 32 * ks);
-            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, hi[ks], acc[ct], 0, 0, 0);
-        }
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const v4i c = *reinterpret_cast<const v4i *>(cs + 32 * (ct0 + ct) + 8 * g + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[ct][4 * g + e] = wadd(wshl(acc[ct][4 * g + e], 8), c[e]);
-        }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const v4i w = *reinterpret_cast<const v4i *>(wrow + (size_t)32 * ct * Kp + 32 * ks);
-            acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, lo[ks], acc[ct], 0, 0, 0);
-        }
-}
-
-// first of the four consecutive channels that accumulator elements 4g..4g+3 of column tile ct hold
-__device__ __forceinline__ int acc_channel(int ct, int g) { return 32 * ct + 8 * g + 4 * ((threadIdx.x & 63) >> 5); }
 
 // ---------------------------------------------------------------------------------------------
 // Encoder: x int32 (N,K) -> relu(dense) int16 (N,H).  fxpmodel.py:331-366, 1263-1266.
