@@ -52,6 +52,7 @@ def main() -> None:
     ap.add_argument("--dim-scale", type=float, default=0.5)
     ap.add_argument("--sparsity", type=float, default=0.0)
     ap.add_argument("--quantization", default="w8a16")
+    ap.add_argument("--input-scale", type=float, default=None, help="scale of the synthetic input (default 1; 300 for w4a8)")
     ap.add_argument("--state-headroom-bits", type=int, default=None,
                     help="extra integer bits of the SSM state in the synthetic qconfig (default 1; 2 for pruned models, whose\n"
                          "fixed-point states drift further from the float calibration)")
@@ -101,8 +102,13 @@ def main() -> None:
     if args.state_headroom_bits is None:
         args.state_headroom_bits = 2 if args.sparsity > 0 else 1
     # one extra integer bit for the (never clipped) SSM state: see synth.make_model(state_headroom_bits)
+    # the 8-bit activation recipe needs a larger input and unit-variance BatchNorm statistics to fit its widths (the
+    # same settings as tests/test_gpu_parity.py's w4a8 case)
+    narrow = args.quantization == "w4a8"
+    in_scale = args.input_scale if args.input_scale is not None else (300.0 if narrow else 1.0)
     md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity,
-                                    calib_L=1024, state_headroom_bits=args.state_headroom_bits)
+                                    calib_L=1024, state_headroom_bits=args.state_headroom_bits, input_scale=in_scale,
+                                    bn_stats="random" if narrow else "calibrated")
     allreduce = None
     if args.global_exponents and world > 1:
         from sparsernns_amd.dist import make_exponent_allreduce
@@ -116,7 +122,7 @@ def main() -> None:
     from sparsernns_amd.engine import InflightRunner
     fxs, ys = [], []
     for lane in range(depth):
-        x = synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane)  # every rank / lane its own batch
+        x = synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane, scale=in_scale)  # every rank / lane its own batch
         fxs.append(fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
                                round_mode=RoundingMode.FLOOR))
         ys.append(torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device=dev))
@@ -252,7 +258,7 @@ def main() -> None:
     scan_big = None
     if rank == 0 and world == 1 and optimistic and not args.no_scan_sweep:
         Bb = 4 * B
-        xb = synth.make_input(Bb, L, dims["d_in"], seed=77)
+        xb = synth.make_input(Bb, L, dims["d_in"], seed=77, scale=in_scale)
         fxb = fxp_from_fp(xb, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
                           round_mode=RoundingMode.FLOOR)
         yb = torch.empty((Bb, L, dims["d_out"]), dtype=torch.int32, device=dev)
