@@ -76,6 +76,10 @@ def main(argv=None) -> int:
     ap.add_argument("--verify", action="store_true",
                     help="run_verification: op-by-op forward with store_intermediates, compared with the fused engine")
     ap.add_argument("--export", type=str, default=None, help="write the integer model as PREFIX.npz / PREFIX.json")
+    ap.add_argument("--check-golden", action="store_true",
+                    help="--model only: the npz also holds an integer input `x` and the output `y` some other implementation "
+                         "produced for it (the reference's fxpmodel_io.pkl through tools/convert_reference_export.py, or "
+                         "tests/golden/*.npz): run x and compare bit for bit")
     args = ap.parse_args(argv)
 
     import torch
@@ -102,6 +106,20 @@ def main(argv=None) -> int:
         inp_bits, inp_exp, d_in = int(meta["x_bits"]), int(meta["x_exp"]), eng.d_in
     print(f"[fxprun] model: d_in={eng.d_in} H={eng.H} P={eng.P} layers={eng.n_layers} d_out={eng.d_out} "
           f"mfma_fast_path={bool(_lib.lib.s5fxp_model_is_fast(eng._h))}")
+
+    if args.check_golden:
+        if args.synthetic:
+            ap.error("--check-golden needs --model")
+        z = np.load(args.model, allow_pickle=False)
+        if "x" not in z.files or "y" not in z.files:
+            print("[fxprun] --check-golden: the npz holds no x / y", file=sys.stderr)
+            return 2
+        gx, gy = z["x"].astype(np.int32), z["y"].astype(np.int32)
+        got = eng.forward(FxpArray(torch.from_numpy(gx).to(eng.device), inp_bits, inp_exp))
+        same = bool(np.array_equal(got.numpy(), gy))
+        cfg_ok = ("y_bits" not in meta) or (got.bits, got.exp) == (int(meta["y_bits"]), int(meta["y_exp"]))
+        print(f"[fxprun] golden check: {gx.shape} -> {gy.shape}: bit-exact={same} output config matches={cfg_ok}")
+        return 0 if (same and cfg_ok) else 1
 
     if args.inputs:
         x = np.load(args.inputs, allow_pickle=False).astype(np.float32)

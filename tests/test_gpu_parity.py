@@ -538,3 +538,15 @@ def test_forward_is_capturable_in_a_hip_graph():
         torch.cuda.synchronize()
         assert np.array_equal(y.cpu().numpy(), ref)
         assert not int(eng.status[0].item()) & _lib.ST_REDO
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b_bnscale", "ndns05_short"])
+def test_fxprun_cli_golden_check(name):
+    """--check-golden on the committed fixtures (the same format tools/convert_reference_export.py writes from the
+    reference's own --export files)."""
+    import os
+    from sparsernns_amd import fxprun
+
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    assert fxprun.main(["--model", os.path.join(g, name + ".npz"), "--meta", os.path.join(g, name + ".json"),
+                        "--check-golden"]) == 0
