@@ -215,7 +215,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                     for (int j = 0; j < 4; ++j) {
                         pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(v2i16, w[j]));
                         pmin = __builtin_elementwise_min(pmin, __builtin_bit_cast(v2i16, w[j]));
-                        const bool keep = ((int32_t)((uint32_t)w[j] << 16) > 0) | ((((uint32_t)w[j] & 0xffffu) == 0) & (w[j] > 0));
+                        // lexicographic (re, im) > (0, 0)  <=>  re * 2^16 + im > 0 (|im| < 2^15 cannot outweigh re != 0; the
+                        // sum wraps only for re = -32768, a value beyond xmax: such a tile raises `redo` and is discarded)
+                        const bool keep = ((int32_t)((uint32_t)w[j] << 16) + (w[j] >> 16)) > 0;
                         w[j] = keep ? w[j] : 0;
                     }
                 } else {
