@@ -185,6 +185,10 @@ def main() -> None:
     # recurrence, four-byte-plane gate kernel), still with `inflight` batches in flight, BEFORE the timed region,
     # and says so in the JSON line.  That is what engine.InflightRunner does by itself after two ST_REDOs.
     fallback_note = None
+    # setup, not warmup: one forward per lane so that every lane's workspace and status words exist and every kernel
+    # has been loaded before anything is timed, however small --warmup / --steps are
+    run(depth, depth)
+    torch.cuda.synchronize()
     probe = max(args.warmup, 1)
     run(probe, depth)
     torch.cuda.synchronize()
