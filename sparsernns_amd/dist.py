@@ -8,8 +8,11 @@ sequences is the data-dependent exponent of the five ``compute_best`` ops per la
 * mode B "per-shard" (default): every rank treats its shard as one reference batch -- exactly what the
   reference computes when it is handed that shard (its recipe batch size is 32, recipes/ndns.json).
   No collective on the data path.
-* mode A "global": the maxima are combined with ``all_reduce(MAX)`` (<= 3 floats per op, 15 ops per
-  forward) so N ranks reproduce, bit for bit, one reference run over the concatenated batch.
+* mode A "global": the maxima are combined with ``all_reduce(MAX)`` so N ranks reproduce, bit for bit, one
+  reference run over the concatenated batch.  What the fast path exchanges per layer: the 2H per-channel
+  extremes of the layer input (every BatchNorm stage is monotone per channel, so the four BatchNorm maxima
+  follow from them -- csrc/mfma_bn.hpp) and the 3 maxima of the residual add: two collectives per layer.
+  The generic path exchanges the <= 3 maxima of each of its five compute_best ops.
 
 Outputs are gathered with one ``all_gather`` (RCCL over xGMI) when the caller wants them on every rank.
 """
@@ -30,13 +33,21 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def make_exponent_allreduce(group: Optional[dist.ProcessGroup] = None) -> Callable[[torch.Tensor], None]:
+def make_exponent_allreduce(group: Optional[dist.ProcessGroup] = None, via_host: bool = False) -> Callable[[torch.Tensor], None]:
     """Hook for ``Engine.enqueue(..., allreduce=...)``: element-wise MAX over ranks of the float32 maxima
     of one compute_best op.  The tensor is a view into the engine's workspace; the collective is
-    stream-ordered behind the reduction kernel that produced it."""
+    stream-ordered behind the reduction kernel that produced it.
+
+    via_host: for backends that cannot reduce device memory (gloo rehearsals of several ranks on one GPU):
+    the values make a round trip through host memory, which synchronises the stream once per exchange."""
 
     def hook(maxima: torch.Tensor) -> None:
-        dist.all_reduce(maxima, op=dist.ReduceOp.MAX, group=group)
+        if via_host:
+            t = maxima.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            maxima.copy_(t)
+        else:
+            dist.all_reduce(maxima, op=dist.ReduceOp.MAX, group=group)
 
     return hook
 

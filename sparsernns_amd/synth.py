@@ -28,7 +28,10 @@ NDNS_STFT_MEAN = 0.0007  # sparseRNNs/fxprun.py:65
 
 W8A16 = dict(non_ssm_w=8, non_ssm_b=16, non_ssm_act=16, ssm_w=8, ssm_act=16)  # fxprun.py:302-308
 W8A8 = dict(non_ssm_w=8, non_ssm_b=8, non_ssm_act=8, ssm_w=8, ssm_act=8)
-W4A8 = dict(non_ssm_w=4, non_ssm_b=8, non_ssm_act=8, ssm_w=4, ssm_act=8)  # not a reference recipe
+# not a reference recipe.  full_range: exp = fracbits of the calibrated power-of-two scale instead of
+# min(fracbits, bits - 1 - intbits): the reference's rule never spends a fractional bit beyond bits - 1, which is harmless
+# at 16 bits and fatal at 4 (a B-bar tensor with absmax 0.015 would quantise to all zeros at exp 3)
+W4A8 = dict(non_ssm_w=4, non_ssm_b=8, non_ssm_act=8, ssm_w=4, ssm_act=8, full_range=True)
 PRECISIONS = {"w8a16": W8A16, "w8a8": W8A8, "w4a8": W4A8}
 
 
@@ -212,10 +215,10 @@ def fracbits_from_absmax(absmax: float, bits: int) -> int:
     return -int(round(math.log2(absmax / float((1 << (bits - 1)) - 1))))
 
 
-def _entry(absmax: float, bits: int) -> dict:
+def _entry(absmax: float, bits: int, full_range: bool = False) -> dict:
     absmax = max(float(absmax), 1e-12)
     ib, fb = get_intbits(absmax), fracbits_from_absmax(absmax, bits)
-    return dict(absmax=absmax, intbits=ib, signbits=1, fracbits=fb, bits=bits, exp=min(fb, bits - 1 - ib))
+    return dict(absmax=absmax, intbits=ib, signbits=1, fracbits=fb, bits=bits, exp=fb if full_range else min(fb, bits - 1 - ib))
 
 
 def derive_qconfig(modeldict: dict, stats: dict, n_layers: int, precisions: dict = W8A16) -> dict:
@@ -224,6 +227,10 @@ def derive_qconfig(modeldict: dict, stats: dict, n_layers: int, precisions: dict
     layers = [enc[f"layers_{i}"] for i in range(n_layers)]
     wb, bb, ab = precisions["non_ssm_w"], precisions["non_ssm_b"], precisions["non_ssm_act"]
     sw, sa = precisions["ssm_w"], precisions["ssm_act"]
+    full = bool(precisions.get("full_range", False))
+
+    def _entry(absmax, bits):  # noqa: F811 - the recipe's exponent rule
+        return globals()["_entry"](absmax, bits, full)
 
     def dense_cfg(dense_list, inp_absmax, out_absmax):
         w = _entry(max(np.abs(d["kernel"]).max() for d in dense_list), wb)
@@ -295,8 +302,40 @@ def make_model(dim_scale: float = 0.5, seed: int = 1919, quantization: str = "w8
     qc = derive_qconfig(md, stats, dims["n_layers"], PRECISIONS[quantization])
     for k in ("x_re", "x_im"):
         qc["blocks"]["ssm"]["activations"][k]["exp"] -= state_headroom_bits
+    cap_result_exponents(qc)
     _assert_exps_nonnegative(qc)
     return md, qc, dims
+
+
+def cap_result_exponents(qc: dict) -> dict:
+    """Lowers a result exponent that asks for more fractional bits than its operands carry.
+
+    Every product in the model is shifted right by ``e1 + e2 - result_exp`` (fxparray.py:619-621, 662-664); a negative
+    shift is a ``ValueError`` in ``fxp_mul`` and undefined in ``fxp_matmul``.  ``add_target_bits_exp`` never produces
+    one for the reference's 16-bit activation recipes, but with 8-bit activations and 4-bit weights (w4a8,
+    SURVEY.md 8d C5) ``min(fracbits, bits-1-intbits)`` of a small product can exceed what a 4-bit kernel and an
+    8-bit input provide.  Capping the result exponent at the sum of the operand exponents (shift 0: the product is
+    kept exactly) is the calibration a narrow recipe needs; it leaves every w8a16 configuration untouched.
+    """
+    def cap(d, key, limit):
+        if d[key] > limit:
+            d[key] = limit
+
+    for name in ("encoder", "decoder"):
+        cap(qc[name], "out_exp", qc[name]["inp_exp"] + qc[name]["w_exp"])
+    blocks = [qc["blocks"]] + [v for k, v in qc["blocks"].items() if k.startswith("layers_")]
+    for b in blocks:
+        if "ssm" not in b:
+            continue
+        w, a = b["ssm"]["weights"], b["ssm"]["activations"]
+        cap(a["Bu_re"], "exp", a["u"]["exp"] + w["B_re"]["exp"])
+        cap(a["Bu_im"], "exp", a["u"]["exp"] + w["B_im"]["exp"])
+        cap(a["y"], "exp", min(a["x_re"]["exp"] + w["C_re"]["exp"], a["x_im"]["exp"] + w["C_im"]["exp"],
+                               w["D"]["exp"] + a["u"]["exp"]))
+        # a dense layer converts its input only when that is finer than inp_exp (fxpmodel.py:335-347)
+        cap(b["out2"], "out_exp", min(b["out2"]["inp_exp"], a["y"]["exp"]) + b["out2"]["w_exp"])
+        cap(b["multgate"], "res_exp", b["multgate"]["l_exp"] + b["multgate"]["r_exp"])
+    return qc
 
 
 def _assert_exps_nonnegative(tree, path="fxp_qconfig"):
