@@ -312,7 +312,9 @@ def main() -> None:
     # algorithmic bytes stay SURVEY.md 8(d)'s 16*P per frame (the reference's int32 element type); what the kernel
     # actually moves is in `traffic` (PMC) and `stored_bytes_per_launch`
     optimistic = not (allreduce or args.self_contained or exact_mode)
-    scan_kernel = "k_scan_quad_asm16" if optimistic else ("k_scan_quad32_asm" if exact_mode else "k_scan_quad_asm")
+    kinds = {_lib.lib.s5fxp_model_recurrence_kernel(eng._h, i) for i in range(nl)}
+    opt_kernel = {0: "k_scan_lane", 1: "k_scan_quad_asm", 2: "k_scan_quad_asm16", 3: "k_scan_pair_asm"}[max(kinds)]
+    scan_kernel = opt_kernel if optimistic else ("k_scan_quad32_asm" if exact_mode else "k_scan_quad_asm")
     traffic = pmc_traffic(B, L, dims["P"], scan_kernel)
     stored = scan_stored_bytes(scan_kernel, algo_bytes)
     moved = traffic if traffic is not None else stored

@@ -110,6 +110,7 @@ def _load():
         "s5fxp_model_out_exp": (i, [p]),
         "s5fxp_model_out_bits": (i, [p]),
         "s5fxp_model_is_fast": (i, [p]),
+        "s5fxp_model_recurrence_kernel": (i, [p, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale: rebuild
@@ -121,7 +122,7 @@ lib = _load()
 EXPORTED_SYMBOLS = ("s5fxp_version s5fxp_strerror s5fxp_from_fp s5fxp_to_float s5fxp_change_cfg s5fxp_dense s5fxp_dense_csr s5fxp_add "
                     "s5fxp_mul s5fxp_add_cb s5fxp_mul_cb s5fxp_relu s5fxp_sigmoid s5fxp_scan s5fxp_model_blob_bytes "
                     "s5fxp_model_create s5fxp_model_destroy s5fxp_workspace_bytes s5fxp_model_forward "
-                    "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast").split()
+                    "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast s5fxp_model_recurrence_kernel").split()
 
 
 def check(rc: int, what: str = "") -> None:

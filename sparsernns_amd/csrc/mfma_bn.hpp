@@ -389,6 +389,7 @@ struct BprojM2Args {
     int32_t L, TB, H, P;
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
     int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
+    int32_t k_re;        // SM = 2 (pair-native K stream): 2^16 - 2^(16 - A_re_exp), the addend of the negated product
 };
 
 } // namespace s5

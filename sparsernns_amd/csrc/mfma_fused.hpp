@@ -96,7 +96,8 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // sum a*w = Horner over four MFMA passes with the same per-channel constant 128*sum(w) added at each of the three shifts
 // -- all modulo 2^32, which is the reference's int32 matmul (fxparray.py:662).  No range check, complex ReLU through
 // float32 exactly as the reference does it (fxp_prims.hpp crelu).
-template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false>
+// PAIR (with S16): the states come from k_scan_pair_asm in pair-native order (scan_quad.hpp)
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
@@ -205,12 +206,24 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                     continue;
                 }
                 if (S16) {
+                    if (PAIR) {
+                        // one 8-step item per lane of the pair: this thread takes the half with its 4 steps from both.
+                        // lane A: [im0 im2 | re1 re3], lane B: [re0 re2 | im1 im3] (per half)
+                        const int t = t0 + o;
+                        const int16_t *src = reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t >> 3, p, a.TB >> 1, P) << 1) + (t & 4);
+                        const v2i qa = *reinterpret_cast<const v2i *>(src), qb = *reinterpret_cast<const v2i *>(src + 8);
+                        w[0] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x05040100u);
+                        w[1] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x05040100u);
+                        w[2] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x07060302u);
+                        w[3] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x07060302u);
+                    } else {
                     // 16 bytes: re of steps 0..3, then im of steps 0..3, as int16; w[j] = re_j | im_j << 16 by two perms
                     const v4i q4 = *reinterpret_cast<const v4i *>(reinterpret_cast<const int16_t *>(a.xs) + native_word(b0, t0 + o, p, 0, a.TB, P));
                     w[0] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x05040100u);
                     w[1] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x07060302u);
                     w[2] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x05040100u);
                     w[3] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x07060302u);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(v2i16, w[j]));

@@ -46,9 +46,10 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
     nvalid = sr.t_len - tt < FT ? sr.t_len - tt : FT;
 }
 
-// S16: the stream holds int16 (the host has checked that every value fits: Bu bits minus the shift to the state
-// exponent <= 16); one item is then 8 bytes
-template <int KS, int NT, bool TRACE, bool S16 = false>
+// SM (stream mode) 0: int32 scan-native items; 1: int16 items (the host has checked that every value fits: Bu bits minus
+// the shift to the state exponent <= 16; one item is then 8 bytes); 2: the pair kernel's K stream (scan_quad.hpp):
+// K = (Bu << 16) + k in pair-native order, two 8-byte halves per producer lane
+template <int KS, int NT, bool TRACE, int SM = 0>
 __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
 {
     constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
@@ -166,7 +167,15 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }
                         }
-                        if (S16)
+                        if (SM == 2) {
+                            const int32_t kc = cc ? 0 : a.k_re;
+                            int32_t *base = a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC);
+                            const v2i k02 = {(int)wadd(wshl(q[0], 16), kc), (int)wadd(wshl(q[2], 16), kc)};
+                            const v2i k13 = {(int)wadd(wshl(q[1], 16), kc), (int)wadd(wshl(q[3], 16), kc)};
+                            // lane A = [Kim0 Kim2 Kre1 Kre3], lane B = [Kre0 Kre2 Kim1 Kim3]
+                            *reinterpret_cast<v2i *>(base + (cc ? 0 : 4)) = k02;
+                            *reinterpret_cast<v2i *>(base + (cc ? 6 : 2)) = k13;
+                        } else if (SM == 1)
                             *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
                                 pack4_i16(q[0], q[1], q[2], q[3]);
                         else

@@ -276,6 +276,8 @@ struct LayerDev {
     bool b24 = false, c24 = false;
     bool quad_ok = false; // quad recurrence kernel applicable (P % 16 == 0, coefficients fit 24 bits)
     int32_t quad_xmax = 0; // its exactness bound on |state|
+    bool pair_ok = false;  // pair recurrence kernel applicable (scan_quad.hpp k_scan_pair_asm)
+    int32_t pair_xmax = 0; // its exactness bound on |state|
     DenseDev out2;
     int l_bits, l_exp, r_bits, r_exp, res_bits, res_exp, sig_x, sig_y;
     int32_t lut[8];
@@ -362,6 +364,24 @@ void pack_layer(Packer &p, const s5fxp_layer_desc &l, LayerDev &o, bool allow24)
         }
         o.quad_ok = allow24 && (P % 16 == 0) && sre >= 0 && sim >= 0 && sre < 16 && sim < 16 && cmax < (1 << 23);
         o.quad_xmax = (int32_t)std::min<int64_t>(((int64_t(1) << 31) - 1 - 65536) / cmax, (1 << 23) - 1);
+        // pair kernel: Bu is folded into the addend of the own product (always an Ai product), so
+        //   |Ai| * 2^(16-e) * |x| + 2^16 * (bmax + 1) <= 2^31 - 1   and   |Ar| * 2^(16-e) * |x| <= 2^31 - 1
+        // with bmax = the largest |Bu| after the shift to the state exponent (static: its bits minus the shift)
+        const int sh_re = l.ssm.Bu_re_exp - l.ssm.x_re_exp, sh_im = l.ssm.Bu_im_exp - l.ssm.x_im_exp;
+        const int bb_re = l.ssm.Bu_re_bits - sh_re, bb_im = l.ssm.Bu_im_bits - sh_im; // bits of the shifted Bu
+        o.pair_ok = false;
+        if (o.quad_ok && P % 32 == 0 && bb_re >= 1 && bb_re <= 16 && bb_im >= 1 && bb_im <= 16) {
+            const int64_t lim = (int64_t(1) << 31) - 1;
+            int64_t xm = 32766;
+            for (int q = 0; q < P; ++q) {
+                const int64_t ar = std::llabs((long long)l.ssm.A_re[q]), ai = std::llabs((long long)l.ssm.A_im[q]);
+                const int64_t room_re = lim - 65536 * ((int64_t(1) << (bb_re - 1)) + 1), room_im = lim - 65536 * ((int64_t(1) << (bb_im - 1)) + 1);
+                if (ai) xm = std::min({xm, room_re / (ai << sre), room_im / (ai << sim)});
+                if (ar) xm = std::min({xm, lim / (ar << sre), lim / (ar << sim)});
+            }
+            o.pair_xmax = (int32_t)xm;
+            o.pair_ok = xm >= 16384; // below that the quad kernel (bound 32767) is the better optimistic choice
+        }
     }
     pack_dense(p, l.out2, o.out2, allow24);
     o.l_bits = l.l_bits; o.l_exp = l.l_exp; o.r_bits = l.r_bits; o.r_exp = l.r_exp; o.res_bits = l.res_bits;
@@ -398,7 +418,10 @@ int validate(const s5fxp_model_desc *d)
     return S5FXP_OK;
 }
 
-constexpr int SCAN_DEPTH = S5_SCAN_ASM_DEPTH; // time blocks (4 steps each) the quad recurrence kernel keeps in flight
+// time blocks (4 steps each) the recurrence kernels keep in flight: streams are padded to a multiple of it and followed by
+// that many blocks of readable padding (the pair kernel's ring, the deepest, prefetches that far beyond its run)
+constexpr int SCAN_DEPTH = S5_SCANP_ASM_DEPTH;
+static_assert(S5_SCANP_ASM_DEPTH % S5_SCAN_ASM_DEPTH == 0, "one padding rule for all recurrence kernels");
 
 } // namespace
 
@@ -480,6 +503,16 @@ extern "C" int s5fxp_model_out_exp(const s5fxp_model *m) { return m ? m->dec.out
 extern "C" int s5fxp_model_out_bits(const s5fxp_model *m) { return m ? m->dec.out_bits : 0; }
 /* 1 if the int8-MFMA path was packed for this model (it also needs L % 4 == 0 at run time) */
 extern "C" int s5fxp_model_is_fast(const s5fxp_model *m) { return m && m->fast ? 1 : 0; }
+extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
+{
+    if (!m || layer < 0 || layer >= m->n_layers) return -1;
+    const LayerDev &l = m->layers[layer];
+    const s5fxp_ssm_desc &s = l.sd;
+    if (!m->fast) return l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+    if (!l.quad_ok) return 1; // the MFMA path's recurrence is always a quad kernel (32-bit chain when not quad_ok)
+    const bool s16 = s.Bu_re_bits - (s.Bu_re_exp - s.x_re_exp) <= 16 && s.Bu_im_bits - (s.Bu_im_exp - s.x_im_exp) <= 16;
+    return s16 ? (l.pair_ok && !std::getenv("S5FXP_NO_PAIR") ? 3 : 2) : 1;
+}
 
 namespace {
 

@@ -395,6 +395,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
         // B projection's output, of both sides of the recurrence and of the gate kernel's state input
         const bool s16 = defer && quad && !tr && n_chunks == 1 && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
+        // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
+        // per state, four instructions per step; K stream int32 in, int16 states out).  S5FXP_NO_PAIR=1 (tests, profiling)
+        static const bool no_pair = std::getenv("S5FXP_NO_PAIR") != nullptr;
+        const bool pair = s16 && l.pair_ok && !no_pair;
         {
             BprojM2Args a{};
             a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
@@ -403,6 +407,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
+            a.k_re = 65536 - (1 << (16 - s.A_re_exp));
             // phase-split kernel (proj_p.hpp): 64-step tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
             for (int k = 0; k < n_chunks; ++k) {
@@ -413,9 +418,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 if (tr) {
                     if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr);
                     else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr);
+                } else if (pair) {
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 2>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, false, 2>, pgrid, smem, st, a, bthr);
                 } else if (s16) {
-                    if (big) launch_smem(k_bproj_p<6, 8, false, true>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, false, true>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 1>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, false, 1>, pgrid, smem, st, a, bthr);
                 } else {
                     if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr);
                     else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr);
@@ -429,7 +437,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
         if (piped && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[0], 0)))) return rc;
         if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], sst)))) return rc;
-        if (quad) {
+        if (pair) {
+            ScanPairArgs q{};
+            q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            hipLaunchKernelGGL(k_scan_pair_asm, dim3((unsigned)((int64_t)B * (P / 32))), dim3(64), 0, sst, q);
+            xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax; // <= 32766: a saturated int16 state fails the check
+        } else if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
@@ -503,6 +517,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
+                    } else if (direct && pair) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, true>, cg, smem, a, 768);
+                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, true>, cg, smem, a);
+                    } else if (pair) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true, false, 64, false, true>, cg, smem, a, 768);
+                        else launch6g(k_cgate_p<2, 3, false, true, false, 64, false, true>, cg, smem, a);
                     } else if (direct) { // (32-frame tiles with three-wave workgroups were tried: 39 vs 36 us)
                         if (big) launch6g(k_cgate_p<4, 6, false, true, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, false, true, true>, cg, smem, a);

@@ -247,4 +247,63 @@ __global__ __launch_bounds__(64) void k_scan_quad32_asm(ScanQuadArgs a)
                  : S5_SCAN32W_ASM_CLOBBERS);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pair kernel: two lanes per state, four instructions per step (tools/gen_scan_asm.py, "Pair kernel"):
+//     z1 = c_own * x + K               K = (Bu << 16) + k, written ready-made by the B projection (k_bproj_p<.., SM = 2>)
+//     z2 = c_part * x[partner]         DPP read of the partner lane's state
+//     x' = (z1 >> 16) + (z2 >> 16)
+// The lane that holds re computes im' = asr(Ai*re) + asr(Ar*im[partner]) + Bu_im, the lane that holds im computes
+// re' = -asr(Ai*im) + asr(Ar*re[partner]) + Bu_re: a lane's role alternates every step, both own products carry Ai
+// (the negated one with k = 2^16 - 2^(16-e)), both partner products Ar.  Lane A (even) holds re before even steps,
+// lane B im.
+//
+// Exactness: z2 < 2^31 needs |Ar| * 2^(16-e) * |x| < 2^31; z1 needs |Ai| * 2^(16-e) * |x| + 2^16 * (|Bu| + 1) < 2^31.
+// With |Bu| <= bmax known statically (its bits minus the shift to the state exponent) that is a bound |x| <= xmax
+// (pack_layer: LayerDev::pair_xmax), checked by the consumer on every stored state exactly like the quad kernels'
+// bound; states are stored as saturated int16, so a state beyond 16 bits fails the check as well.
+//
+// Streams ("pair-native", a wave's blocks are contiguous so that immediate offsets reach eight of them):
+//   K   int32  word(b, tb, p, lane, slot) = ((((b*PG + p/32)*TB + tb)*32 + p%32)*2 + lane)*4 + slot,  PG = P/32,
+//              slots of a lane = steps [t0, t2, t1, t3] of block tb: lane A = [Kim0, Kim2, Kre1, Kre3],
+//              lane B = [Kre0, Kre2, Kim1, Kim3]  (each producer lane of the B projection writes two 8-byte halves)
+//   xs  int16  half(b, t8, p, lane, j)    = ((((b*PG + p/32)*TB/2 + t8)*32 + p%32)*2 + lane)*8 + j, 8 steps per item:
+//              lane A = [im0 im2 | re1 re3 | im4 im6 | re5 re7], lane B = [re0 re2 | im1 im3 | re4 re6 | im5 im7]
+__device__ __forceinline__ int64_t pair_word(int64_t b, int tb, int p, int TB, int P)
+{
+    return ((((b * (P >> 5) + (p >> 5)) * TB + tb) << 5) + (p & 31)) << 3;
+}
+
+struct ScanPairArgs {
+    const int32_t *k;           // pair-native K stream
+    int16_t *xs;                // pair-native packed states
+    const int32_t *a_re, *a_im; // (P)
+    int32_t B, TB, P;           // TB % S5_SCANP_ASM_DEPTH == 0
+    int32_t ea_re, ea_im;
+};
+
+__global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x); // (b, state group of 32)
+    if (wave >= a.B * (a.P >> 5)) return;
+    const int p = ((wave % (a.P >> 5)) << 5) + (lane >> 1);
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int sre = 16 - a.ea_re, sim = 16 - a.ea_im;
+    const bool laneB = lane & 1;
+    // even steps: lane A holds re -> computes im', lane B holds im -> computes re'; odd steps the other way round
+    const int32_t c_im_own = Ai << sim, c_im_part = Ar << sim, c_re_own = -(Ai << sre), c_re_part = Ar << sre;
+    const int32_t coe = laneB ? c_re_own : c_im_own, cpe = laneB ? c_re_part : c_im_part;
+    const int32_t coo = laneB ? c_im_own : c_re_own, cpo = laneB ? c_im_part : c_re_part;
+    const unsigned long long pin = (unsigned long long)(a.k + (size_t)wave * a.TB * 256),
+                             pout = (unsigned long long)(a.xs + (size_t)wave * a.TB * 256);
+    const unsigned vin = lane * 16 + 4096, vout = vin;
+    const int32_t x0 = 0;
+    unsigned cnt = (unsigned)a.TB / S5_SCANP_ASM_DEPTH;
+    asm volatile(S5_SCANP_ASM_BODY
+                 : [cnt] "+s"(cnt)
+                 : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vin] "v"(vin), [vout] "v"(vout),
+                   [x0] "v"(x0), [pin] "s"(pin), [pout] "s"(pout)
+                 : S5_SCANP_ASM_CLOBBERS);
+}
+
 } // namespace s5

@@ -382,8 +382,10 @@ def test_generated_scan_asm_is_up_to_date(tmp_path):
     t32, _ = gen.emit("S5_SCAN_ASM", gen.Plan(False))
     t16, _ = gen.emit("S5_SCAN16_ASM", gen.Plan(True))
     t32w, _ = gen.emit("S5_SCAN32W_ASM", gen.Plan(False, wide=True))
+    tp, _ = gen.emit_pair()
     have = open(os.path.join(ROOT, "sparsernns_amd", "csrc", "scan_quad_asm.inc")).read()
-    assert t32 in have and t16 in have and t32w in have and f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have
+    assert t32 in have and t16 in have and t32w in have and tp in have
+    assert f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have and f"#define S5_SCANP_ASM_DEPTH {gen.PAIR_DEPTH}" in have
 
 
 def test_config0_float_forward_plumbing_and_fixed_point_tracks_it():

@@ -727,3 +727,50 @@ def test_bench_starts_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, cwd=root,
                          env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stdout + bad.stderr)
+
+
+def test_pair_recurrence_kernel_is_selected_and_guarded():
+    """The optimistic forward of the NDNS models runs the pair kernel (two lanes per state, Bu folded into the multiply's
+    addend: csrc/scan_quad.hpp).  Its exactness bound on |state| is tighter than the quad kernel's; inputs scaled so that
+    the states pass it must come back through the exact kernels with the oracle's result, and with S5FXP_NO_PAIR=1 the
+    quad kernels must still give the same outputs."""
+    import os
+    import subprocess
+    import sys
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    for ds in (0.5, 1.0):
+        md, qc, dims = _make(dict(dim_scale=ds, calib_L=256, state_headroom_bits=1))
+        model = build_regression_model(md, qc, dims["n_layers"])
+        eng = model.engine()
+        assert [_lib.lib.s5fxp_model_recurrence_kernel(eng._h, i) for i in range(3)] == [3, 3, 3]
+        cm = cref.CModel(model.export())
+        seen = set()
+        for scale in (1.0, 2.0, 2.6, 3.2, 4.0):   # from well inside the bound to beyond 16 bits
+            fx = _input(qc, dims, 2, 640, seed=int(10 * scale), scale=scale)
+            ref, _, _, tr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+            top = max(max(int(np.abs(t["xs_re"]).max()), int(np.abs(t["xs_im"]).max())) for t in tr)
+            y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))
+            assert np.array_equal(y.numpy(), ref), (ds, scale, top)
+            seen.add(top > 32767)
+        assert seen == {False, True}, "the sweep must cover states inside and outside 16 bits"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\n"
+            "from oracle import cref, fxp_oracle as O\n"
+            "from sparsernns_amd import _lib, synth\n"
+            "from sparsernns_amd.fxparray import FxpArray\n"
+            "from sparsernns_amd.fxpmodel import build_regression_model\n"
+            "md, qc, dims = synth.make_model(0.5, calib_L=256, state_headroom_bits=1)\n"
+            "model = build_regression_model(md, qc, dims['n_layers'])\n"
+            "eng = model.engine()\n"
+            "assert _lib.lib.s5fxp_model_recurrence_kernel(eng._h, 0) == 2\n"
+            "x = synth.make_input(2, 640, dims['d_in'], seed=4)\n"
+            "fx = O.from_fp(x, qc['encoder']['inp_bits'], qc['encoder']['inp_exp'], True, O.FLOOR)\n"
+            "y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))\n"
+            "assert np.array_equal(y.numpy(), cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)[0])\n"
+            "print('quad16 path ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, S5FXP_NO_PAIR="1"))
+    assert r.returncode == 0 and "quad16 path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

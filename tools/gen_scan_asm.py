@@ -148,6 +148,167 @@ def body(P):
     return b
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Pair kernel (round 2): TWO lanes per state, Bu folded into the multiply's addend, cross-lane read at the INPUT
+# of the step.  tools/ubench_chain (profiles/r02_ubench_chain*.log) measured, for a lone wave: a step costs
+# 4 cycles per instruction + 2, a memory instruction in a filler slot costs 6 (global_*) to 9 (buffer_*) cycles
+# more than a nop.  Round 1's step is 5 instructions (mad, sdwa-add, 2 fillers for the DPP hazard, dpp-add); this
+# one is 4:
+#     F                                   filler slot: the two wait states a DPP read of x needs after its write
+#     z1 = c_own * x + K                  v_mad_i32_i24; K = (Bu << 16) + k comes ready-made from the B projection
+#     z2 = c_part * x[partner]            v_mul_i32_i24_dpp quad_perm:[1,0,3,2]
+#     x' = (z1 >> 16) + (z2 >> 16)        v_add_u32_sdwa, both sources sign-extended WORD_1
+# The lane that holds re computes im' (own product Ai*re, partner product Ar*im) and vice versa, so the roles of a
+# lane alternate every step and both own products carry Ai (the negated one with its k) -- see scan_quad.hpp.
+# Memory: one global_load_dwordx4 per 4 steps (K for 4 steps), one global_store_dwordx4 per 8 steps (8 states as
+# saturated int16), immediate offsets inside 8 KB windows.  DEPTH blocks of 4 steps are kept in flight.
+PAIR_DEPTH = 32
+PAIR_SLOT = (0, 2, 1, 3)  # ring register used by step 0..3 of a block: items are [t0, t2, t1, t3]
+
+
+class PairPlan:
+    R0 = 32
+    O = R0 + 4 * PAIR_DEPTH       # two output tuples of 8 (one 8-step group each)
+    PK = O + 16                   # two packed tuples of 4
+    Z1 = PK + 8
+    Z2 = Z1 + 1
+    VIN = Z2 + 1                  # running byte offsets (per lane) of the load / store windows
+    VOUT = VIN + 1
+    SCR = VOUT + 1                # target of the peeled group's dummy load
+    LAST = SCR
+
+
+def pair_iteration(first: bool):
+    """One loop iteration = PAIR_DEPTH blocks.  Returns a list of (text, kind) with kind in
+    {'valu','load','store','wait','other'}; waits carry the ring slots they must cover."""
+    Q = PairPlan
+    D = PAIR_DEPTH
+    out = []
+    for i in range(D):
+        g, half = i // 2, i % 2
+        cur, prev = g & 1, (g & 1) ^ 1
+        oc, op = Q.O + 8 * cur, Q.O + 8 * prev
+        pk = Q.PK + 4 * prev          # the tuple that receives / stores the PREVIOUS group
+        refill = (i - 1) % D          # ring slot whose block was consumed last
+        n_blk = refill                # position of that slot's next block in the load sequence (mod 8 window)
+        ld = (f"global_load_dwordx4 v[{Q.R0 + 4 * refill}:{Q.R0 + 4 * refill + 3}], v{Q.VIN}, %[pin] "
+              f"offset:{((n_blk % 8) - 4) * 1024}")
+        dead = first and g == 0       # no previous group yet
+        nop = ("s_nop 0", "other")
+        bump_in = n_blk % 8 == 7
+        if first and i == 0:
+            # slot D-1 still holds block D-1 of the prologue: nothing to refill yet (a dummy load keeps the count of
+            # memory instructions in flight equal to the steady state's, which the vmcnt values assume)
+            ld, bump_in = f"global_load_dword v{Q.SCR}, v{Q.VIN}, %[pin] offset:-4096", False
+        if half == 0:
+            fills = [(ld, "load"),
+                     nop if dead else (f"v_cvt_pk_i16_i32 v{pk}, v{op}, v{op + 2}", "valu"),
+                     nop if dead else (f"v_cvt_pk_i16_i32 v{pk + 1}, v{op + 1}, v{op + 3}", "valu"),
+                     nop if dead else (f"v_cvt_pk_i16_i32 v{pk + 2}, v{op + 4}, v{op + 6}", "valu")]
+        else:
+            gp = (g - 1) % (D // 2)   # index of the previous group in the store sequence
+            st = f"global_store_dwordx4 v{Q.VOUT}, v[{pk}:{pk + 3}], %[pout] offset:{((gp % 8) - 4) * 1024}"
+            fills = [(ld, "load"),
+                     nop if dead else (f"v_cvt_pk_i16_i32 v{pk + 3}, v{op + 5}, v{op + 7}", "valu"),
+                     # the peeled first group keeps the memory-instruction count of the steady state (vmcnt bookkeeping)
+                     (f"global_load_dword v{Q.SCR}, v{Q.VIN}, %[pin] offset:-4096", "store") if dead else (st, "store"),
+                     (f"WAIT {i}", "wait") if i % 4 == 3 else nop]
+        for s_ in range(4):
+            j = 4 * half + s_
+            xprev = oc + j - 1 if j > 0 else op + 7
+            par = "e" if j % 2 == 0 else "o"
+            out.append(fills[s_])
+            if fills[s_][1] == "load" and bump_in:
+                out.append((f"v_add_u32 v{Q.VIN}, 0x2000, v{Q.VIN}", "valu"))
+            if fills[s_][1] == "store" and not dead and gp % 8 == 7:
+                out.append((f"v_add_u32 v{Q.VOUT}, 0x2000, v{Q.VOUT}", "valu"))
+            k = Q.R0 + 4 * i + PAIR_SLOT[s_]
+            out.append((f"v_mad_i32_i24 v{Q.Z1}, %[co{par}], v{xprev}, v{k}", "valu"))
+            out.append((f"v_mul_i32_i24_dpp v{Q.Z2}, v{xprev}, %[cp{par}] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "valu"))
+            out.append((f"v_add_u32_sdwa v{oc + j}, sext(v{Q.Z1}), sext(v{Q.Z2}) dst_sel:DWORD dst_unused:UNUSED_PAD "
+                        f"src0_sel:WORD_1 src1_sel:WORD_1", "valu"))
+    return out
+
+
+def pair_resolve_waits(it, like=None):
+    """`WAIT i` sits in block i (i % 4 == 3) and must cover ring slots i+1 .. i+4 (the next four blocks; slot D is slot 0
+    of the next iteration).  Slot j is refilled in block j+1, so the data of a slot whose refill comes LATER in the
+    iteration than the wait was loaded one iteration earlier.  vmcnt = memory instructions issued after the youngest of
+    those loads, minus one: the peeled first iteration replaces group 0's store by a dummy load to keep the count, the
+    margin covers the prologue's different interleaving."""
+    D = PAIR_DEPTH
+    if like is not None:  # the peeled iteration: same positions, same values as the steady state
+        skel = lambda seq: [k for _, k in seq if k in ("load", "store", "wait")]
+        assert skel(it) == skel(like)  # same memory / wait skeleton
+        vals = iter([t for t in pair_resolve_waits(like) if t.startswith("s_waitcnt")])
+        return [next(vals) if k == "wait" else t for t, k in it]
+    mem = [idx for idx, (t, k) in enumerate(it) if k in ("load", "store")]
+    load_pos = {}
+    for idx, (t, k) in enumerate(it):
+        if k == "load":
+            load_pos[(int(t.split("v[")[1].split(":")[0]) - PairPlan.R0) // 4] = idx
+    res = []
+    for idx, (t, k) in enumerate(it):
+        if k != "wait":
+            res.append(t)
+            continue
+        i = int(t.split()[1])
+        worst = None
+        for slot in range(i + 1, i + 5):
+            p = load_pos[slot % D]
+            if p > idx:   # issued in the previous iteration
+                n = sum(1 for m in mem if m > p) + sum(1 for m in mem if m < idx)
+            else:         # issued earlier in this iteration (the wrap: slots of the next iteration's first blocks)
+                n = sum(1 for m in mem if p < m < idx)
+            worst = n if worst is None else min(worst, n)
+        assert 0 <= worst - 1 <= 63, worst
+        res.append(f"s_waitcnt vmcnt({worst - 1})")
+    return res
+
+
+def pair_body():
+    Q = PairPlan
+    D = PAIR_DEPTH
+    b = []
+    b.append(f"v_mov_b32 v{Q.O + 15}, %[x0]")       # "previous" tuple of group 0 is tuple 1: its last register is x_(-1)
+    b.append(f"v_mov_b32 v{Q.VIN}, %[vin]")
+    b.append(f"v_mov_b32 v{Q.VOUT}, %[vout]")
+    b.append("s_setprio 3")
+    for n in range(D):                               # prologue: blocks 0 .. D-1
+        b.append(f"global_load_dwordx4 v[{Q.R0 + 4 * n}:{Q.R0 + 4 * n + 3}], v{Q.VIN}, %[pin] offset:{((n % 8) - 4) * 1024}")
+        if n % 8 == 7:
+            b.append(f"v_add_u32 v{Q.VIN}, 0x2000, v{Q.VIN}")
+    b.append("s_waitcnt vmcnt(0)")
+    b += pair_resolve_waits(pair_iteration(True), like=pair_iteration(False))
+    b.append("s_sub_u32 %[cnt], %[cnt], 1")
+    b.append("s_cmp_eq_u32 %[cnt], 0")
+    b.append("s_cbranch_scc1 2f")
+    b.append("1:")
+    b += pair_resolve_waits(pair_iteration(False))
+    b.append("s_sub_u32 %[cnt], %[cnt], 1")
+    b.append("s_cmp_lg_u32 %[cnt], 0")
+    b.append("s_cbranch_scc1 1b")
+    b.append("2:")
+    last_g = D // 2 - 1
+    o, pk = Q.O + 8 * (last_g & 1), Q.PK + 4 * (last_g & 1)
+    b.append(f"v_cvt_pk_i16_i32 v{pk}, v{o}, v{o + 2}")
+    b.append(f"v_cvt_pk_i16_i32 v{pk + 1}, v{o + 1}, v{o + 3}")
+    b.append(f"v_cvt_pk_i16_i32 v{pk + 2}, v{o + 4}, v{o + 6}")
+    b.append(f"v_cvt_pk_i16_i32 v{pk + 3}, v{o + 5}, v{o + 7}")
+    b.append("s_nop 1")
+    b.append(f"global_store_dwordx4 v{Q.VOUT}, v[{pk}:{pk + 3}], %[pout] offset:{((last_g % 8) - 4) * 1024}")
+    b.append("s_waitcnt vmcnt(0)")
+    return b
+
+
+def emit_pair(name="S5_SCANP_ASM"):
+    b = pair_body()
+    clobbers = ", ".join(f'"v{r}"' for r in range(PairPlan.R0, PairPlan.LAST + 1))
+    text = "\n".join(f'    "{l}\\n\\t"' for l in b)
+    return (f"#define {name}_BODY \\\n{text.replace(chr(10), ' ' + chr(92) + chr(10))}\n"
+            f'#define {name}_CLOBBERS {clobbers}, "memory", "scc"\n'), len(b)
+
+
 def emit(name, P):
     b = body(P)
     clobbers = ", ".join(f'"v{r}"' for r in range(P.R0, P.LAST + 1))
@@ -160,17 +321,22 @@ def main():
     t32, n32 = emit("S5_SCAN_ASM", Plan(False))
     t16, n16 = emit("S5_SCAN16_ASM", Plan(True))
     t32w, n32w = emit("S5_SCAN32W_ASM", Plan(False, wide=True))
+    tp, npair = emit_pair()
     out = f"""// GENERATED by tools/gen_scan_asm.py -- do not edit.  DEPTH = {DEPTH}.
 // Operands: [ca] [cb] [ka] [kb] [voff] [x0] VGPR inputs; [rin] [rout] 128-bit SGPR buffer descriptors;
 // [stride] SGPR bytes per time block; [sld] [sst] [cnt] SGPR read-write (load / store offsets, iterations).
 // S5_SCAN32W_ASM_BODY (exact 32-bit chain): [ca] [cb] are the plain multipliers, plus [sa] [sb] shifts, [ma] [mb] negation
 // masks (0 / -1) and [oa] [ob] = mask & 1, all VGPR inputs; [ka] [kb] unused.
+// S5_SCANP_ASM_BODY (pair kernel, {PAIR_DEPTH} blocks in flight): [coe] [cpe] [coo] [cpo] own / partner multipliers of even / odd steps,
+// [vin] [vout] per-lane byte offsets (lane * 16 + 4096), [x0] VGPR inputs; [pin] [pout] 64-bit SGPR base addresses of this
+// wave's run of the K stream / the packed state stream; [cnt] SGPR read-write (iterations of {PAIR_DEPTH} blocks).
 #define S5_SCAN_ASM_DEPTH {DEPTH}
-{t32}{t16}{t32w}"""
+#define S5_SCANP_ASM_DEPTH {PAIR_DEPTH}
+{t32}{t16}{t32w}{tp}"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparsernns_amd", "csrc", "scan_quad_asm.inc")
     with open(path, "w") as f:
         f.write(out)
-    print("wrote", os.path.normpath(path), n32, "+", n16, "+", n32w, "instructions")
+    print("wrote", os.path.normpath(path), n32, "+", n16, "+", n32w, "+", npair, "instructions")
 
 
 if __name__ == "__main__":

@@ -110,6 +110,48 @@ def blk1(i):
 var("S1_mem_exact4", sum((blk1(i) for i in range(4)), []))
 
 
+# ---- round 2: what does ONE memory instruction per 4-step block cost, by kind?  Base = S2 with nop fillers (18.0).
+def pattern(fills, per_step=(MAD, MULDPP, ADD_HH)):
+    """16 steps; fills = list of 16 filler instructions (one per step, first slot)"""
+    return [[f] + list(per_step) for f in fills]
+
+
+def every4(x, others=NOP):
+    return [x if i % 4 == 0 else others for i in range(16)]
+
+
+LDS_RD = "ds_read_b128 v[20:23], v7"
+LDS_RD64 = "ds_read_b64 v[20:21], v7"
+LDS_WR64 = "ds_write_b64 v7, v[28:29]"
+LDS_WR128 = "ds_write_b128 v7, v[24:27]"
+var("F_load_x4", pattern(every4("buffer_load_dwordx4 v[20:23], v9, s[8:11], s16 offen")))
+var("F_load_x2", pattern(every4("buffer_load_dwordx2 v[20:21], v8, s[8:11], s16 offen")))
+var("F_load_x1", pattern(every4("buffer_load_dword v20, v8, s[8:11], s16 offen")))
+var("F_load_x4_off", pattern(every4("buffer_load_dwordx4 v[20:23], off, s[8:11], s16")))
+var("F_gload_x4", pattern(every4("global_load_dwordx4 v[20:23], v9, s[8:9]")))
+var("F_store_x4", pattern(every4("buffer_store_dwordx4 v[24:27], v9, s[12:15], s17 offen")))
+var("F_store_x2", pattern(every4("buffer_store_dwordx2 v[28:29], v8, s[12:15], s17 offen")))
+var("F_store_x1", pattern(every4("buffer_store_dword v28, v8, s[12:15], s17 offen")))
+var("F_store_x2_off", pattern(every4("buffer_store_dwordx2 v[28:29], off, s[12:15], s17")))
+var("F_gstore_x2", pattern(every4("global_store_dwordx2 v8, v[28:29], s[12:13]")))
+var("F_cvt", pattern(every4(PK)))
+var("F_ds_rd128", pattern(every4(LDS_RD)))
+var("F_ds_rd64", pattern(every4(LDS_RD64)))
+var("F_ds_wr64", pattern(every4(LDS_WR64)))
+var("F_ds_wr128", pattern(every4(LDS_WR128)))
+var("F_ds_rd128_wr64", pattern([LDS_RD, NOP, NOP, LDS_WR64] * 4))
+var("F_ds_rd128_pk_pk_wr64", pattern([LDS_RD, PK, PK2, LDS_WR64] * 4))
+var("F_ld_st_x4x2", pattern(["buffer_load_dwordx4 v[20:23], v9, s[8:11], s16 offen", NOP, NOP, "buffer_store_dwordx2 v[28:29], v8, s[12:15], s17 offen"] * 4))
+var("F_ld_only_all", pattern(["buffer_load_dwordx4 v[20:23], v9, s[8:11], s16 offen"] * 16))
+var("F_barrier_per16", pattern(["s_barrier"] + [NOP] * 15))
+var("F_waitcnt_each4", pattern(every4("s_waitcnt vmcnt(0) lgkmcnt(0)")))
+# a load every 8 steps, a store every 8 steps (wider items)
+var("F_ld4_st8", pattern((["buffer_load_dwordx4 v[20:23], v9, s[8:11], s16 offen", NOP, NOP, NOP,
+                           "buffer_load_dwordx4 v[20:23], v9, s[8:11], s16 offen", NOP, NOP, "buffer_store_dwordx4 v[24:27], v9, s[12:15], s17 offen"]) * 2))
+# round-1 shape with its real fillers, for reference
+var("CUR_ld_st", [[MAD, SDWA_Q_SAME, ("buffer_load_dwordx2 v[20:21], v8, s[8:11], s16 offen" if i % 4 == 0 else SADD if i % 4 == 1 else "buffer_store_dwordx2 v[28:29], v8, s[12:15], s17 offen" if i % 4 == 2 else NOP), (PK if i % 4 < 2 else NOP), DPPADD] for i in range(16)])
+
+
 def main():
     out = ["// GENERATED by tools/gen_ubench_chain.py -- do not edit."]
     names = []

@@ -32,7 +32,9 @@ struct Args {
 #define UB_KERNEL(NAME, NINS)                                                                                          \
     __global__ __launch_bounds__(64) void k_##NAME(Args a)                                                             \
     {                                                                                                                  \
+        __shared__ int lds_buf[4096];                                                                                  \
         const int lane = threadIdx.x;                                                                                  \
+        lds_buf[lane] = lane;                                                                                          \
         const unsigned wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);                                         \
         const unsigned long long bin = (unsigned long long)(a.in + (size_t)wave * (1u << 18)),                         \
                                  bout = (unsigned long long)(a.out + (size_t)wave * (1u << 17));                       \
@@ -47,7 +49,7 @@ struct Args {
                      "s_mov_b32 s12, %[w0]\n\ts_mov_b32 s13, %[w1]\n\ts_mov_b32 s14, %[w2]\n\ts_mov_b32 s15, %[r3]\n\t" \
                      "s_mov_b32 s16, 0\n\ts_mov_b32 s17, 0\n\ts_mov_b32 s18, 0x1000\n\ts_mov_b32 s19, 0x800\n\t"       \
                      "v_mov_b32 v2, %[c2]\n\tv_mov_b32 v3, %[c3]\n\tv_mov_b32 v4, %[c4]\n\tv_mov_b32 v5, %[c5]\n\t"     \
-                     "v_mov_b32 v9, %[vo16]\n\tv_mov_b32 v8, %[vo8]\n\tv_mov_b32 v10, %[x]\n\t"                         \
+                     "v_mov_b32 v9, %[vo16]\n\tv_mov_b32 v8, %[vo8]\n\tv_mov_b32 v7, %[vo16]\n\tv_mov_b32 v10, %[x]\n\t"                         \
                      "v_mov_b32 v11, 0\n\tv_mov_b32 v12, 0\n\tv_mov_b32 v13, 0\n\tv_mov_b32 v14, 1\n\tv_mov_b32 v15, 2\n\t" \
                      "v_mov_b32 v20, 0\n\tv_mov_b32 v21, 0\n\tv_mov_b32 v22, 0\n\tv_mov_b32 v23, 0\n\t"                 \
                      "v_mov_b32 v24, 0\n\tv_mov_b32 v25, 0\n\tv_mov_b32 v26, 0\n\tv_mov_b32 v27, 0\n\t"                 \
@@ -61,11 +63,11 @@ struct Args {
                      : [t0] "=&s"(t0), [t1] "=&s"(t1), [cnt] "+s"(cnt), [x] "+v"(x)                                    \
                      : [r0] "s"(r0), [r1] "s"(r1), [r2] "s"(r2), [r3] "s"(r3), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), \
                        [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [vo16] "v"(vo16), [vo8] "v"(vo8)         \
-                     : "v2", "v3", "v4", "v5", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21", "v22", \
+                     : "v2", "v3", "v4", "v5", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v20", "v21", "v22", \
                        "v23", "v24", "v25", "v26", "v27", "v28", "v29", "s8", "s9", "s10", "s11", "s12", "s13", "s14",  \
                        "s15", "s16", "s17", "s18", "s19", "memory", "scc");                                            \
         if (lane == 0) a.cyc[wave] = t1 - t0;                                                                          \
-        if (x == 0x12345678) a.sink[0] = x;                                                                            \
+        if (x == 0x12345678) a.sink[0] = x + lds_buf[lane + 64];                                                                          \
     }
 
 UB_ALL(UB_KERNEL)
