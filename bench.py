@@ -75,7 +75,7 @@ def launch_ranks(n: int) -> int:
 def scan_stored_bytes(kernel: str, algo_bytes: int) -> int:
     """Bytes the recurrence kernel's two streams hold (what it loads + stores when nothing is re-read): int32 in and
     out = the algorithmic 16*P per frame; the optimistic kernels keep int16 on one or both sides."""
-    per16 = {"k_scan_quad_asm16": 8, "k_scan_pair_asm": 12}  # of 16: int16 in + int16 out; int32 in + int16 out
+    per16 = {"k_scan_quad_asm16": 8, "k_scan_pairl_asm": 8, "k_scan_pair_asm": 12}  # of 16: int16 in + int16 out; int32 in + int16 out
     return algo_bytes * per16.get(kernel, 16) // 16
 
 
@@ -313,7 +313,7 @@ def main() -> None:
     # actually moves is in `traffic` (PMC) and `stored_bytes_per_launch`
     optimistic = not (allreduce or args.self_contained or exact_mode)
     kinds = {_lib.lib.s5fxp_model_recurrence_kernel(eng._h, i) for i in range(nl)}
-    opt_kernel = {0: "k_scan_lane", 1: "k_scan_quad_asm", 2: "k_scan_quad_asm16", 3: "k_scan_pair_asm"}[max(kinds)]
+    opt_kernel = {0: "k_scan_lane", 1: "k_scan_quad_asm", 2: "k_scan_quad_asm16", 3: "k_scan_pair_asm", 4: "k_scan_pairl_asm"}[max(kinds)]
     scan_kernel = opt_kernel if optimistic else ("k_scan_quad32_asm" if exact_mode else "k_scan_quad_asm")
     traffic = pmc_traffic(B, L, dims["P"], scan_kernel)
     stored = scan_stored_bytes(scan_kernel, algo_bytes)

@@ -239,7 +239,8 @@ int s5fxp_model_out_bits(const s5fxp_model *m);
 int s5fxp_model_is_fast(const s5fxp_model *m);
 /* Which recurrence kernel an optimistic forward (S5FXP_FWD_DEFER_REDO) runs for `layer`:
  * 0 one lane per state (generic), 1 quad kernel with int32 streams, 2 quad kernel with int16 streams,
- * 3 pair kernel (int32 K stream in, int16 states out; sparseRNNs/fxpmodel.py:147-172 in four instructions per step).
+ * 3 pair kernel (int32 K stream in, int16 states out; sparseRNNs/fxpmodel.py:147-172 in four instructions per step),
+ * 4 the same pair kernel fed through LDS by a helper wave from an int16 Bu stream (the default where it applies).
  * -1: bad argument.  The exact re-run (S5FXP_FWD_EXACT) always uses the 32-bit quad kernel on the MFMA path. */
 int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer);
 

@@ -48,7 +48,8 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
 
 // SM (stream mode) 0: int32 scan-native items; 1: int16 items (the host has checked that every value fits: Bu bits minus
 // the shift to the state exponent <= 16; one item is then 8 bytes); 2: the pair kernel's K stream (scan_quad.hpp):
-// K = (Bu << 16) + k in pair-native order, two 8-byte halves per producer lane
+// K = (Bu << 16) + k in pair-native order, one 16-byte item per producer lane; 3: the LDS-fed pair kernel's int16 Bu
+// stream (pair16-native), one 8-byte item per producer lane
 template <int KS, int NT, bool TRACE, int SM = 0>
 __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
 {
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
             const int col = 32 * (wave + NT * c) + r;
-            const int cc = col >= PC ? 1 : 0, p = col - cc * PC;
+            // SM >= 2: the weight columns are packed so that lanes r and r ^ 16 hold re and im of the SAME state
+            // (pack_fast: bproj_pair); otherwise columns [0, P) are re, [P, 2P) im
+            const int cc = SM >= 2 ? (r >> 4) : (col >= PC ? 1 : 0), p = SM >= 2 ? 16 * (wave + NT * c) + (r & 15) : col - cc * PC;
             const int rs = cc ? a.rs_im : a.rs_re, bits = cc ? a.bim_bits : a.bre_bits, sh = cc ? a.sh_im : a.sh_re;
             const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
 #pragma unroll
@@ -167,14 +170,26 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }
                         }
-                        if (SM == 2) {
+                        if (SM == 3) {
+                            // the same item as SM == 2 (steps 0 and 2 from the other component's lane), as plain int16 Bu: the
+                            // recurrence kernel's helper wave forms K.  h = 0 / 1 lanes hold the two blocks of a pair, so one
+                            // wave store fills 512 contiguous bytes
+                            const int32_t o0 = __builtin_amdgcn_ds_swizzle(q[0], 0x401f), o2 = __builtin_amdgcn_ds_swizzle(q[2], 0x401f);
+                            *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, (t0 + o) >> 2, p, cc, a.TB, PC)) =
+                                pack4_i16(o0, o2, q[1], q[3]);
+                        } else if (SM == 2) {
+                            // K = (Bu << 16) + k.  Pair-native items: lane A = [Kim0 Kim2 Kre1 Kre3], lane B = [Kre0 Kre2
+                            // Kim1 Kim3]: steps 0 and 2 come from the OTHER component's lane (r ^ 16, ds_swizzle), steps 1
+                            // and 3 are this lane's own; the re lane writes item A, the im lane item B -- one 16-byte store
+                            // each, 512 contiguous bytes per half wave
                             const int32_t kc = cc ? 0 : a.k_re;
-                            int32_t *base = a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC);
-                            const v2i k02 = {(int)wadd(wshl(q[0], 16), kc), (int)wadd(wshl(q[2], 16), kc)};
-                            const v2i k13 = {(int)wadd(wshl(q[1], 16), kc), (int)wadd(wshl(q[3], 16), kc)};
-                            // lane A = [Kim0 Kim2 Kre1 Kre3], lane B = [Kre0 Kre2 Kim1 Kim3]
-                            *reinterpret_cast<v2i *>(base + (cc ? 0 : 4)) = k02;
-                            *reinterpret_cast<v2i *>(base + (cc ? 6 : 2)) = k13;
+                            const int32_t k0 = wadd(wshl(q[0], 16), kc), k2 = wadd(wshl(q[2], 16), kc);
+                            v4i item;
+                            item[0] = __builtin_amdgcn_ds_swizzle(k0, 0x401f);
+                            item[1] = __builtin_amdgcn_ds_swizzle(k2, 0x401f);
+                            item[2] = wadd(wshl(q[1], 16), kc);
+                            item[3] = wadd(wshl(q[3], 16), kc);
+                            *reinterpret_cast<v4i *>(a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC) + 4 * cc) = item;
                         } else if (SM == 1)
                             *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
                                 pack4_i16(q[0], q[1], q[2], q[3]);

@@ -511,7 +511,7 @@ extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
     if (!m->fast) return l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
     if (!l.quad_ok) return 1; // the MFMA path's recurrence is always a quad kernel (32-bit chain when not quad_ok)
     const bool s16 = s.Bu_re_bits - (s.Bu_re_exp - s.x_re_exp) <= 16 && s.Bu_im_bits - (s.Bu_im_exp - s.x_im_exp) <= 16;
-    return s16 ? (l.pair_ok && !std::getenv("S5FXP_NO_PAIR") ? 3 : 2) : 1;
+    return s16 ? (l.pair_ok && !std::getenv("S5FXP_NO_PAIR") ? (std::getenv("S5FXP_PAIR_GLOBAL") ? 3 : 4) : 2) : 1;
 }
 
 namespace {

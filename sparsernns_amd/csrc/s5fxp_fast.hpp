@@ -11,6 +11,7 @@ struct MfmaWDev {
 
 struct FastLayer {
     MfmaWDev bproj, cre, cim, out2;
+    MfmaWDev bproj_pair; // the same weights with re / im of a state 16 columns apart inside one 32-column tile
     const int32_t *Dpad = nullptr; // [Np]
     const int32_t *sigtab = nullptr; // [2][7 << sig_x] (mfma_fused.hpp k_cgate_p)
     const int16_t *sigdir = nullptr; // [1 << sigdir_bits] when the sigmoid input has <= 12 bits (DIRECT)
@@ -151,6 +152,10 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
         const int H = s.H, P = s.P;
         pack_mfma(p, [&](int k, int ch) { return ch < P ? s.B_re[(size_t)ch * H + k] : s.B_im[(size_t)(ch - P) * H + k]; }, H,
                   2 * P, o.bproj);
+        pack_mfma(p, [&](int k, int ch) {
+                      const int st = 16 * (ch / 32) + (ch & 15);
+                      return (ch & 16) ? s.B_im[(size_t)st * H + k] : s.B_re[(size_t)st * H + k];
+                  }, H, 2 * P, o.bproj_pair);
         pack_mfma(p, [&](int k, int ch) { return s.C_re[(size_t)ch * P + k]; }, P, H, o.cre);
         pack_mfma(p, [&](int k, int ch) { return s.C_im[(size_t)ch * P + k]; }, P, H, o.cim);
         pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2);
@@ -399,6 +404,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // per state, four instructions per step; K stream int32 in, int16 states out).  S5FXP_NO_PAIR=1 (tests, profiling)
         static const bool no_pair = std::getenv("S5FXP_NO_PAIR") != nullptr;
         const bool pair = s16 && l.pair_ok && !no_pair;
+        // the pair kernel is fed either from an int16 Bu stream through LDS by a helper wave (default: the HBM bytes of the
+        // quad16 path) or from an int32 K stream in global memory (S5FXP_PAIR_GLOBAL=1)
+        static const bool pair_global = std::getenv("S5FXP_PAIR_GLOBAL") != nullptr;
+        const bool pairl = pair && !pair_global;
         {
             BprojM2Args a{};
             a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
@@ -418,7 +427,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 if (tr) {
                     if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr);
                     else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr);
+                } else if (pairl) {
+                    a.w = fl.bproj_pair.w;
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 3>, pgrid, smem, st, a, bthr);
+                    else launch_smem(k_bproj_p<3, 4, false, 3>, pgrid, smem, st, a, bthr);
                 } else if (pair) {
+                    a.w = fl.bproj_pair.w;
                     if (big) launch_smem(k_bproj_p<6, 8, false, 2>, pgrid, smem, st, a, bthr);
                     else launch_smem(k_bproj_p<3, 4, false, 2>, pgrid, smem, st, a, bthr);
                 } else if (s16) {
@@ -437,7 +451,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
         if (piped && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[0], 0)))) return rc;
         if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], sst)))) return rc;
-        if (pair) {
+        if (pairl) {
+            ScanPairLArgs q{};
+            q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            // one helper wave: a second one lands on the computing wave's half of the CU's LDS store path and costs more
+            // than it helps (tools/ubench_pair: 44.2 vs 42.8 us); S5FXP_PAIRL_HELPERS2=1 keeps the variant reachable
+            static const bool two_helpers = std::getenv("S5FXP_PAIRL_HELPERS2") != nullptr;
+            if (two_helpers) hipLaunchKernelGGL(k_scan_pairl_asm<2>, dim3((unsigned)((int64_t)B * (P / 32))), dim3(192), 0, sst, q);
+            else hipLaunchKernelGGL(k_scan_pairl_asm<1>, dim3((unsigned)((int64_t)B * (P / 32))), dim3(128), 0, sst, q);
+            xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax;
+        } else if (pair) {
             ScanPairArgs q{};
             q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;

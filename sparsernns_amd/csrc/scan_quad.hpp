@@ -35,6 +35,7 @@
 namespace s5 {
 
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
 
 // word index of (sequence b, step t, state p, component c) in a scan-native stream with TB blocks/sequence
 __device__ __forceinline__ int64_t native_word(int64_t b, int t, int p, int c, int TB, int P)
@@ -304,6 +305,140 @@ __global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
                  : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vin] "v"(vin), [vout] "v"(vout),
                    [x0] "v"(x0), [pin] "s"(pin), [pout] "s"(pout)
                  : S5_SCANP_ASM_CLOBBERS);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same pair recurrence fed from LDS: workgroup = the computing wave + a HELPER wave on another SIMD of the CU.
+// The helper streams the layer's Bu as int16 (half the bytes of the int32 K stream), expands K = (Bu << 16) + k and
+// writes it where the computing wave's ds_read_b128 expects it; three LDS buffers of S5_SCANPL_BLOCKS blocks rotate,
+// one s_barrier per buffer.  The computing wave's loop is tools/gen_scan_asm.py "pairl".
+//
+// Bu stream ("pair16-native", written by k_bproj_p<.., SM = 3>): per wave run (b, state group of 32), per PAIR of
+// blocks, per lane l = 2 * (p % 32) + {A, B}: 8 halfwords = [block 2j: t0 t2 t1 t3 | block 2j+1: t0 t2 t1 t3] -- one
+// coalesced 1 KB line per block pair, 16 bytes per helper lane.
+__device__ __forceinline__ int64_t pair16_half(int64_t b, int tb, int p, int lane_sel, int TB, int P)
+{
+    return ((((b * (P >> 5) + (p >> 5)) * (TB >> 1) + (tb >> 1)) << 6) + 2 * (p & 31) + lane_sel) * 8 + 4 * (tb & 1);
+}
+
+struct ScanPairLArgs {
+    const int16_t *b16;         // pair16-native Bu stream (already shifted to the state exponent)
+    int16_t *xs;                // pair-native packed states
+    const int32_t *a_re, *a_im; // (P)
+    int32_t B, TB, P;           // TB % S5_SCANPL_BLOCKS == 0
+    int32_t ea_re, ea_im;
+    int32_t dbg;                // tools/ubench_pair.hip only: 1 = the helper skips its loads, 2 = it only meets the barriers
+};
+
+template <int NHELP> // helper waves per workgroup (1 or 2): each expands an equal share of every iteration's blocks
+__global__ __launch_bounds__(64 * (1 + NHELP)) void k_scan_pairl_asm(ScanPairLArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int32_t kbuf[3 * S5_SCANPL_BUF / 4];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: recurrence, 1: helper
+    const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);         // (b, state group of 32)
+    const int n_it = a.TB / S5_SCANPL_BLOCKS;
+    const int sre = 16 - a.ea_re;
+    const bool laneB = lane & 1;
+    if (role >= 1) {
+        // ---- helper: iteration k+2 goes into buffer (k+2) % 3 while the recurrence works on k
+        constexpr int ALLP = S5_SCANPL_BLOCKS / 2, PAIRS = ALLP / NHELP; // 16-byte items per lane and iteration: all / mine
+        const int j0 = (role - 1) * PAIRS;
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(a.b16) + ((size_t)wave * (a.TB >> 1) + j0) * 64 + lane;
+        const int32_t k_re = 65536 - (1 << sre);
+        const int32_t kE = laneB ? k_re : 0, kO = laneB ? 0 : k_re; // even steps: lane B computes re' (which carries k)
+        // Four register sets: the loads of an iteration are issued four rounds (~2.5 us of recurrence) before they are used.
+        // The loads and their waits are spelled in asm: across this loop's back edge the compiler's vmcnt bookkeeping
+        // falls back to "wait for everything", which puts a whole HBM latency into every round (ubench_pair: 59 us
+        // instead of 40).  Loads return in order, every step issues exactly PAIRS loads after waiting for the oldest
+        // set, so "all but the youngest 3 * PAIRS" is precisely that set.  Past the end the last iteration is
+        // re-read and expanded into a buffer nobody reads any more: no conditional memory instruction anywhere.
+        static_assert(ALLP == 8 && (NHELP == 1 || NHELP == 2), "asm below moves eight or four 16-byte items per lane and iteration");
+        i32x4 r0[PAIRS], r1[PAIRS], r2[PAIRS], r3[PAIRS];
+        auto fetch = [&](i32x4(&r)[PAIRS], int it) {
+            it = it < n_it ? it : n_it - 1;
+            const i32x4 *ptr = src + ((size_t)it * ALLP + 4) * 64; // +-4 KB immediate offsets around the middle
+            if constexpr (NHELP == 2) {
+                if (a.dbg == 0)
+                    asm volatile("global_load_dwordx4 %0, %4, off offset:-4096 nt\n\tglobal_load_dwordx4 %1, %4, off offset:-3072 nt\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:-2048 nt\n\tglobal_load_dwordx4 %3, %4, off offset:-1024 nt"
+                                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+                                 : "v"(ptr)
+                                 : "memory");
+            } else if (a.dbg == 0)
+                asm volatile("global_load_dwordx4 %0, %8, off offset:-4096 nt\n\tglobal_load_dwordx4 %1, %8, off offset:-3072 nt\n\t"
+                             "global_load_dwordx4 %2, %8, off offset:-2048 nt\n\tglobal_load_dwordx4 %3, %8, off offset:-1024 nt\n\t"
+                             "global_load_dwordx4 %4, %8, off nt\n\tglobal_load_dwordx4 %5, %8, off offset:1024 nt\n\t"
+                             "global_load_dwordx4 %6, %8, off offset:2048 nt\n\tglobal_load_dwordx4 %7, %8, off offset:3072 nt"
+                             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                             : "v"(ptr)
+                             : "memory");
+        };
+        auto ready = [&](i32x4(&r)[PAIRS]) { // the oldest of the four sets has landed
+            if constexpr (NHELP == 2)
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(24)"
+                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             :
+                             : "memory");
+        };
+        auto expand = [&](const i32x4(&r)[PAIRS], int it) {
+            if (a.dbg == 2) return;
+            int32_t *dst = kbuf + (it % 3) * (S5_SCANPL_BUF / 4) + j0 * 512 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < PAIRS; ++j) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) { // [t0 t2 | t1 t3] halfword pairs of block 2j + h
+                    const uint32_t d0 = (uint32_t)r[j][2 * h], d1 = (uint32_t)r[j][2 * h + 1];
+                    i32x4 k;
+                    k[0] = (int)((d0 << 16) + (uint32_t)kE);
+                    k[1] = (int)((d0 & 0xffff0000u) | (uint32_t)kE);
+                    k[2] = (int)((d1 << 16) + (uint32_t)kO);
+                    k[3] = (int)((d1 & 0xffff0000u) | (uint32_t)kO);
+                    *reinterpret_cast<i32x4 *>(dst + (2 * j + h) * 256) = k;
+                }
+            }
+        };
+        auto meet = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the LDS writes have landed
+            __builtin_amdgcn_s_barrier();
+        };
+#pragma unroll
+        for (int j = 0; j < PAIRS; ++j) r0[j] = r1[j] = r2[j] = r3[j] = i32x4{0, 0, 0, 0};
+        fetch(r0, 0); fetch(r1, 1); fetch(r2, 2); fetch(r3, 3);
+        ready(r0); expand(r0, 0); fetch(r0, 4);
+        ready(r1); expand(r1, 1); fetch(r1, 5);
+        meet();
+        // round k (the recurrence works on iteration k): iteration k+2 goes into LDS from set (k+2) % 4, which then
+        // receives iteration k+6
+        for (int k = 0; k < n_it; k += 4) {
+            ready(r2); expand(r2, k + 2); fetch(r2, k + 6); meet();
+            if (k + 1 >= n_it) break;
+            ready(r3); expand(r3, k + 3); fetch(r3, k + 7); meet();
+            if (k + 2 >= n_it) break;
+            ready(r0); expand(r0, k + 4); fetch(r0, k + 8); meet();
+            if (k + 3 >= n_it) break;
+            ready(r1); expand(r1, k + 5); fetch(r1, k + 9); meet();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may still be landing in registers when the wave ends
+        return;
+    }
+    const int sim = 16 - a.ea_im;
+    const int p = ((wave % (a.P >> 5)) << 5) + (lane >> 1);
+    const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
+    const int32_t c_im_own = Ai << sim, c_im_part = Ar << sim, c_re_own = -(Ai << sre), c_re_part = Ar << sre;
+    const int32_t coe = laneB ? c_re_own : c_im_own, cpe = laneB ? c_re_part : c_im_part;
+    const int32_t coo = laneB ? c_im_own : c_re_own, cpo = laneB ? c_im_part : c_re_part;
+    const unsigned long long pout = (unsigned long long)(a.xs + (size_t)wave * a.TB * 256);
+    const unsigned vlds = (unsigned)(size_t)kbuf + lane * 16, vout = lane * 16 + 4096;
+    const int32_t x0 = 0;
+    unsigned cnt = (unsigned)n_it;
+    asm volatile(S5_SCANPL_ASM_BODY
+                 : [cnt] "+s"(cnt)
+                 : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vlds] "v"(vlds), [vout] "v"(vout),
+                   [x0] "v"(x0), [pout] "s"(pout)
+                 : S5_SCANPL_ASM_CLOBBERS);
 }
 
 } // namespace s5

@@ -745,7 +745,7 @@ def test_pair_recurrence_kernel_is_selected_and_guarded():
         md, qc, dims = _make(dict(dim_scale=ds, calib_L=256, state_headroom_bits=1))
         model = build_regression_model(md, qc, dims["n_layers"])
         eng = model.engine()
-        assert [_lib.lib.s5fxp_model_recurrence_kernel(eng._h, i) for i in range(3)] == [3, 3, 3]
+        assert [_lib.lib.s5fxp_model_recurrence_kernel(eng._h, i) for i in range(3)] == [4, 4, 4]
         cm = cref.CModel(model.export())
         seen = set()
         for scale in (1.0, 2.0, 2.6, 3.2, 4.0):   # from well inside the bound to beyond 16 bits
@@ -774,3 +774,9 @@ def test_pair_recurrence_kernel_is_selected_and_guarded():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, S5FXP_NO_PAIR="1"))
     assert r.returncode == 0 and "quad16 path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # the pair kernel's other feeds: the int32 K stream in global memory, and two helper waves
+    code2 = code.replace("== 2", "in (3, 4)").replace("quad16 path ok", "pair variant ok")
+    for var in ("S5FXP_PAIR_GLOBAL", "S5FXP_PAIRL_HELPERS2"):
+        r = subprocess.run([sys.executable, "-c", code2], cwd=root, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **{var: "1"}))
+        assert r.returncode == 0 and "pair variant ok" in r.stdout, var + r.stdout[-2000:] + r.stderr[-3000:]

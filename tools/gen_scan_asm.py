@@ -309,6 +309,118 @@ def emit_pair(name="S5_SCANP_ASM"):
             f'#define {name}_CLOBBERS {clobbers}, "memory", "scc"\n'), len(b)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Pair kernel fed from LDS ("pairl"): the same step, but K comes from a ring of three LDS buffers that a HELPER
+# wave of the same workgroup fills from an int16 Bu stream (scan_quad.hpp k_scan_pairl_asm): the stream in HBM stays
+# 16 bit (half the bytes of the int32 K stream), the expansion K = (Bu << 16) + k costs the helper's issue slots, not
+# this wave's.  ds_read_b128 costs the computing wave what global_load_dwordx4 does (ubench: +6 cycles per instruction).
+# One iteration = PAIRL_BLOCKS blocks = one LDS buffer; s_barrier at the end of every iteration; the register ring
+# (PAIRL_RING blocks) prefetches across the iteration boundary, which is why there are three buffers: the helper fills
+# iteration k+2 while this wave works on k and prefetches from k+1.
+PAIRL_BLOCKS = 16
+PAIRL_RING = 8
+PAIRL_BUF = PAIRL_BLOCKS * 1024
+
+
+class PairLPlan:
+    R0 = 32
+    O = R0 + 4 * PAIRL_RING
+    PK = O + 16
+    Z1 = PK + 8
+    Z2 = Z1 + 1
+    VCUR = Z2 + 1                 # lane * 16 + base of this iteration's LDS buffer
+    VNXT = VCUR + 1               # ... of the next iteration's
+    VOUT = VNXT + 1
+    T0 = VOUT + 1
+    LAST = T0
+
+
+def pairl_iteration(first: bool):
+    Q = PairLPlan
+    D, RD = PAIRL_BLOCKS, PAIRL_RING
+    out = []
+    for i in range(D):
+        g, half = i // 2, i % 2
+        cur, prev = g & 1, (g & 1) ^ 1
+        oc, op = Q.O + 8 * cur, Q.O + 8 * prev
+        pk = Q.PK + 4 * prev
+        slot = (i - 1) % RD                     # D % RD == 0: block i lives in ring slot i % RD
+        j = i - 1 + RD                          # the block that slot receives
+        src = (Q.VCUR, j) if j < D else (Q.VNXT, j - D)
+        ld = f"ds_read_b128 v[{Q.R0 + 4 * slot}:{Q.R0 + 4 * slot + 3}], v{src[0]} offset:{src[1] * 1024}"
+        nop = "s_nop 0"
+        if first and i == 0:
+            ld = nop                            # the prologue has filled the whole ring
+        dead = first and g == 0
+        gp = (g - 1) % (D // 2)
+        if half == 0:
+            fills = [ld,
+                     nop if dead else f"v_cvt_pk_i16_i32 v{pk}, v{op}, v{op + 2}",
+                     nop if dead else f"v_cvt_pk_i16_i32 v{pk + 1}, v{op + 1}, v{op + 3}",
+                     nop if dead else f"v_cvt_pk_i16_i32 v{pk + 2}, v{op + 4}, v{op + 6}"]
+        else:
+            fills = [ld,
+                     nop if dead else f"v_cvt_pk_i16_i32 v{pk + 3}, v{op + 5}, v{op + 7}",
+                     nop if dead else f"global_store_dwordx4 v{Q.VOUT}, v[{pk}:{pk + 3}], %[pout] offset:{((gp % 8) - 4) * 1024}",
+                     # ring slots (i+1) % RD, (i+2) % RD are next: their reads were issued RD-2 and RD-3 blocks ago; the reads
+                     # issued since then are those of blocks i+4-RD .. i -> RD-3, minus one of margin
+                     f"s_waitcnt lgkmcnt({RD - 4})"]
+        for s_ in range(4):
+            jj = 4 * half + s_
+            xprev = oc + jj - 1 if jj > 0 else op + 7
+            par = "e" if jj % 2 == 0 else "o"
+            out.append(fills[s_])
+            if fills[s_].startswith("global_store") and gp % 8 == 7:
+                out.append(f"v_add_u32 v{Q.VOUT}, 0x2000, v{Q.VOUT}")
+            k = Q.R0 + 4 * (i % RD) + PAIR_SLOT[s_]
+            out.append(f"v_mad_i32_i24 v{Q.Z1}, %[co{par}], v{xprev}, v{k}")
+            out.append(f"v_mul_i32_i24_dpp v{Q.Z2}, v{xprev}, %[cp{par}] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+            out.append(f"v_add_u32_sdwa v{oc + jj}, sext(v{Q.Z1}), sext(v{Q.Z2}) dst_sel:DWORD dst_unused:UNUSED_PAD "
+                       f"src0_sel:WORD_1 src1_sel:WORD_1")
+    # end of the iteration: the next buffer becomes the current one, the one after it (mod 3 buffers) the next; then meet the
+    # helper, which has by now filled the buffer after that
+    out += [f"v_mov_b32 v{Q.VCUR}, v{Q.VNXT}",
+            f"v_add_u32 v{Q.T0}, {PAIRL_BUF}, v{Q.VNXT}",
+            f"v_subrev_u32 v{Q.VNXT}, {3 * PAIRL_BUF}, v{Q.T0}",
+            f"v_min_u32 v{Q.VNXT}, v{Q.VNXT}, v{Q.T0}",
+            "s_barrier"]
+    return out
+
+
+def pairl_body():
+    Q = PairLPlan
+    D, RD = PAIRL_BLOCKS, PAIRL_RING
+    assert D % RD == 0 and (D // 2) % 8 == 0 or D // 2 == 8
+    b = [f"v_mov_b32 v{Q.O + 15}, %[x0]",
+         f"v_mov_b32 v{Q.VCUR}, %[vlds]",
+         f"v_add_u32 v{Q.VNXT}, {PAIRL_BUF}, v{Q.VCUR}",
+         f"v_mov_b32 v{Q.VOUT}, %[vout]",
+         "s_setprio 3",
+         "s_barrier"]                             # the helper has filled iterations 0 and 1
+    for n in range(RD):
+        b.append(f"ds_read_b128 v[{Q.R0 + 4 * n}:{Q.R0 + 4 * n + 3}], v{Q.VCUR} offset:{n * 1024}")
+    b.append("s_waitcnt lgkmcnt(0)")
+    b += pairl_iteration(True)
+    b += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 2f", "1:"]
+    b += pairl_iteration(False)
+    b += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "2:"]
+    last_g = D // 2 - 1
+    o, pk = Q.O + 8 * (last_g & 1), Q.PK + 4 * (last_g & 1)
+    b += [f"v_cvt_pk_i16_i32 v{pk}, v{o}, v{o + 2}", f"v_cvt_pk_i16_i32 v{pk + 1}, v{o + 1}, v{o + 3}",
+          f"v_cvt_pk_i16_i32 v{pk + 2}, v{o + 4}, v{o + 6}", f"v_cvt_pk_i16_i32 v{pk + 3}, v{o + 5}, v{o + 7}", "s_nop 1",
+          f"global_store_dwordx4 v{Q.VOUT}, v[{pk}:{pk + 3}], %[pout] offset:{((last_g % 8) - 4) * 1024}",
+          "s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    return b
+
+
+def emit_pairl(name="S5_SCANPL_ASM"):
+    b = pairl_body()
+    clobbers = ", ".join(f'"v{r}"' for r in range(PairLPlan.R0, PairLPlan.LAST + 1))
+    text = "\n".join(f'    "{l}\\n\\t"' for l in b)
+    return (f"#define {name}_BODY \\\n{text.replace(chr(10), ' ' + chr(92) + chr(10))}\n"
+            f'#define {name}_CLOBBERS {clobbers}, "memory", "scc"\n'), len(b)
+
+
 def emit(name, P):
     b = body(P)
     clobbers = ", ".join(f'"v{r}"' for r in range(P.R0, P.LAST + 1))
@@ -322,6 +434,7 @@ def main():
     t16, n16 = emit("S5_SCAN16_ASM", Plan(True))
     t32w, n32w = emit("S5_SCAN32W_ASM", Plan(False, wide=True))
     tp, npair = emit_pair()
+    tpl, npairl = emit_pairl()
     out = f"""// GENERATED by tools/gen_scan_asm.py -- do not edit.  DEPTH = {DEPTH}.
 // Operands: [ca] [cb] [ka] [kb] [voff] [x0] VGPR inputs; [rin] [rout] 128-bit SGPR buffer descriptors;
 // [stride] SGPR bytes per time block; [sld] [sst] [cnt] SGPR read-write (load / store offsets, iterations).
@@ -331,12 +444,16 @@ def main():
 // [vin] [vout] per-lane byte offsets (lane * 16 + 4096), [x0] VGPR inputs; [pin] [pout] 64-bit SGPR base addresses of this
 // wave's run of the K stream / the packed state stream; [cnt] SGPR read-write (iterations of {PAIR_DEPTH} blocks).
 #define S5_SCAN_ASM_DEPTH {DEPTH}
+// S5_SCANPL_ASM_BODY (pair kernel fed from LDS): [vlds] = lane * 16 (byte address in LDS buffer 0) instead of [vin] / [pin];
+// {PAIRL_BLOCKS} blocks per iteration and LDS buffer, three buffers of {PAIRL_BUF} bytes, one s_barrier per iteration (+ one up front).
 #define S5_SCANP_ASM_DEPTH {PAIR_DEPTH}
-{t32}{t16}{t32w}{tp}"""
+#define S5_SCANPL_BLOCKS {PAIRL_BLOCKS}
+#define S5_SCANPL_BUF {PAIRL_BUF}
+{t32}{t16}{t32w}{tp}{tpl}"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparsernns_amd", "csrc", "scan_quad_asm.inc")
     with open(path, "w") as f:
         f.write(out)
-    print("wrote", os.path.normpath(path), n32, "+", n16, "+", n32w, "+", npair, "instructions")
+    print("wrote", os.path.normpath(path), n32, "+", n16, "+", n32w, "+", npair, "+", npairl, "instructions")
 
 
 if __name__ == "__main__":
