@@ -223,6 +223,16 @@ typedef struct {
      * `stream` immediately before / after layer l's recurrence kernel(s). NULL entries are skipped. */
     void **scan_events;
     int32_t flags; /* S5FXP_FWD_* */
+    /* Streaming (sparseRNNs/fxpmodel.py:147-172: the step function's carry is an explicit argument; the reference's
+     * recurrent_loop always starts it at zero, :196-207).  Device arrays [n_layers][2][B][P] int32 (re plane, im plane
+     * per layer) or NULL: state_in = the SSM states the recurrences start from (NULL: zeros), state_out = where the
+     * states after the last frame are left (NULL: not wanted).  Feeding a sequence chunk by chunk with the carry gives,
+     * per chunk, what the reference computes for that chunk started from that carry -- every chunk is its own
+     * compute_best batch, so the exponents (and with them the low bits) can differ from one pass over the whole
+     * sequence.  With S5FXP_FWD_DEFER_REDO keep state_in and state_out apart: a forward that comes back with
+     * S5FXP_ST_REDO has left an unusable state_out, and its repeat needs the old state_in. */
+    const int32_t *state_in;
+    int32_t *state_out;
 } s5fxp_forward_opts;
 
 /* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.

@@ -70,6 +70,8 @@ def lib():
         _lib.ref_forward.restype = C.c_int
         _lib.ref_forward.argtypes = [C.POINTER(RefModel), I32P, C.c_int, C.c_int, C.c_int, C.c_int, I32P,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(RefLayerTrace), C.c_int]
+        _lib.ref_forward_state.restype = C.c_int
+        _lib.ref_forward_state.argtypes = _lib.ref_forward.argtypes + [I32P]
         _lib.ref_num_threads.restype = C.c_int
     return _lib
 
@@ -146,9 +148,10 @@ class CModel:
         d.out_bits, d.out_exp = int(q["out_bits"]), int(q["out_exp"])
         return d
 
-    def forward(self, x: np.ndarray, x_bits: int, x_exp: int, trace: bool = False, nthreads: int = 0
-                ) -> Tuple[np.ndarray, int, int, Optional[List[Dict[str, np.ndarray]]]]:
-        """x: int32 (B,L,d_in) or (L,d_in).  Returns (y, y_bits, y_exp, traces)."""
+    def forward(self, x: np.ndarray, x_bits: int, x_exp: int, trace: bool = False, nthreads: int = 0,
+                state: Optional[np.ndarray] = None) -> Tuple[np.ndarray, int, int, Optional[List[Dict[str, np.ndarray]]]]:
+        """x: int32 (B,L,d_in) or (L,d_in).  Returns (y, y_bits, y_exp, traces).
+        state: None, or a C-contiguous int32 array (n_layers, 2, B, P), read and replaced in place (the streaming carry)."""
         x = np.ascontiguousarray(x, dtype=np.int32)
         shp = x.shape
         B, L = (1, shp[0]) if x.ndim == 2 else shp[:2]
@@ -166,9 +169,12 @@ class CModel:
                     setattr(tr_structs[i], k, d[k].ctypes.data_as(I32P))
                 traces.append(d)
         yb, ye = C.c_int(0), C.c_int(0)
-        rc = lib().ref_forward(C.byref(self.model), x.ctypes.data_as(I32P), x_bits, x_exp, B, L,
-                               y.ctypes.data_as(I32P), C.byref(yb), C.byref(ye),
-                               C.cast(tr_structs, C.POINTER(RefLayerTrace)) if trace else None, nthreads)
+        if state is not None:
+            assert state.dtype == np.int32 and state.flags["C_CONTIGUOUS"] and state.shape == (self.n_layers, 2, B, self.P)
+        rc = lib().ref_forward_state(C.byref(self.model), x.ctypes.data_as(I32P), x_bits, x_exp, B, L,
+                                     y.ctypes.data_as(I32P), C.byref(yb), C.byref(ye),
+                                     C.cast(tr_structs, C.POINTER(RefLayerTrace)) if trace else None, nthreads,
+                                     state.ctypes.data_as(I32P) if state is not None else None)
         if rc == -2:
             raise ValueError("negative / out-of-range shift (invalid result_exp)")
         if rc != 0:

@@ -322,8 +322,10 @@ def sigmoid_apply(x: Fx, x_exp: int, y_exp: int, lut: np.ndarray, n_exp: int = 3
     return Fx(yy, x.bits, y_exp, True)
 
 
-def scan(bu_re: Fx, bu_im: Fx, a_re: Fx, a_im: Fx, x_re_exp: int, x_im_exp: int) -> Tuple[np.ndarray, np.ndarray]:
-    """fxpmodel.py:147-208.  bu_*: (..., L, P); a_*: (P,).  Sequential in L, no clip."""
+def scan(bu_re: Fx, bu_im: Fx, a_re: Fx, a_im: Fx, x_re_exp: int, x_im_exp: int, x0=None) -> Tuple[np.ndarray, np.ndarray]:
+    """fxpmodel.py:147-208.  bu_*: (..., L, P); a_*: (P,).  Sequential in L, no clip.
+    x0: optional (re, im) int32 arrays (..., P), the carry the step function starts from (fxpmodel.py:147-172 makes the
+    carry explicit; recurrent_loop always passes zeros, :196-207) -- the streaming API's state."""
     L = bu_re.data.shape[-2]
 
     def shiftto(v, e_from, e_to):  # fxpmodel.py:158-167
@@ -333,6 +335,8 @@ def scan(bu_re: Fx, bu_im: Fx, a_re: Fx, a_im: Fx, x_re_exp: int, x_im_exp: int)
     bi = shiftto(bu_im.data, bu_im.exp, x_im_exp)
     xr = np.zeros(bu_re.data.shape[:-2] + bu_re.data.shape[-1:], dtype=I32)
     xi = np.zeros_like(xr)
+    if x0 is not None:
+        xr, xi = _i32(x0[0]).reshape(xr.shape).copy(), _i32(x0[1]).reshape(xi.shape).copy()
     out_r = np.empty_like(bu_re.data)
     out_i = np.empty_like(bu_im.data)
     ar, ai = a_re.data, a_im.data
@@ -393,13 +397,17 @@ class SSM:
         self.C_re, self.C_im = q(C.real, "C_re"), q(C.imag, "C_im")
         self.D = q(md["D"], "D")
 
-    def __call__(self, x: Fx, inter: Optional[dict] = None):
+    def __call__(self, x: Fx, inter: Optional[dict] = None, state=None):
+        """state: None, or a two-element list [re, im] of (..., P) int32 arrays: the recurrence starts from it and it is
+        replaced by the state after the last step (raw, before the complex ReLU)."""
         act = self.qc["activations"]
         u = change_cfg(x, act["u"]["bits"], act["u"]["exp"], True)
         tr = lambda f: Fx(f.data.T, f.bits, f.exp, f.signed)
         bu_re = matmul(u, tr(self.B_re), act["Bu_re"]["bits"], act["Bu_re"]["exp"])
         bu_im = matmul(u, tr(self.B_im), act["Bu_im"]["bits"], act["Bu_im"]["exp"])
-        xr, xi = scan(bu_re, bu_im, self.A_re, self.A_im, act["x_re"]["exp"], act["x_im"]["exp"])
+        xr, xi = scan(bu_re, bu_im, self.A_re, self.A_im, act["x_re"]["exp"], act["x_im"]["exp"], x0=state)
+        if state is not None:
+            state[0], state[1] = xr[..., -1, :].copy(), xi[..., -1, :].copy()
         xs_re = Fx(xr, act["x_re"]["bits"], act["x_re"]["exp"], True)
         xs_im = Fx(xi, act["x_im"]["bits"], act["x_im"]["exp"], True)
         rr, ri = complex_relu(xs_re, xs_im)
@@ -456,13 +464,13 @@ class SequenceLayer:
         self.sig_y_exp = qc["out2"]["out_bits"] - 2
         self.lut = sigmoid_lut(self.sig_x_exp, self.sig_y_exp)
 
-    def __call__(self, x: Fx, inter: Optional[dict] = None) -> Fx:
+    def __call__(self, x: Fx, inter: Optional[dict] = None, state=None) -> Fx:
         mg = self.qc["multgate"]
         skip = x
         n_i = {} if inter is not None else None
         m_i = {} if inter is not None else None
         t = self.norm(x, n_i)
-        y, _ = self.mixer(t, m_i)
+        y, _ = self.mixer(t, m_i, state)
         x1 = relu(y)
         g_in = self.out2(x1)
         g = sigmoid_apply(g_in, self.sig_x_exp, self.sig_y_exp, self.lut)
@@ -485,20 +493,26 @@ class RegressionModel:
         self.layers = [SequenceLayer(enc[f"layers_{i}"], fxp_qconfig["blocks"], i) for i in range(n_layers)]
         self.decoder = Dense(modeldict["decoder"], fxp_qconfig["decoder"])
 
-    def __call__(self, x: Fx, inter: Optional[dict] = None) -> Fx:
+    def __call__(self, x: Fx, inter: Optional[dict] = None, state=None) -> Fx:
+        """state: None, or a list with one [re, im] pair per layer (see SSM.__call__), updated in place: feeding a
+        sequence chunk by chunk with the same list is the streaming use (every chunk is its own compute_best batch)."""
         e = self.encoder(x)
         h = relu(e)
         if inter is not None:
             inter["pre_encoder"], inter["encoder_output"], inter["encoder_output_relu"] = x, e, h
         for i, layer in enumerate(self.layers):
             li = {} if inter is not None else None
-            h = layer(h, li)
+            h = layer(h, li, state[i] if state is not None else None)
             if inter is not None:
                 inter[f"layers_{i}"] = li
         y = self.decoder(h)
         if inter is not None:
             inter["output"] = y
         return y
+
+    def zero_state(self, batch_shape=()) -> list:
+        P = self.layers[0].mixer.A_re.data.shape[0]
+        return [[np.zeros(tuple(batch_shape) + (P,), dtype=I32), np.zeros(tuple(batch_shape) + (P,), dtype=I32)] for _ in self.layers]
 
     # -- integer export: the layout of fxpmodel.py export() (368-393, 819-847, 946-968, 1163-1207)
     def export(self) -> dict:

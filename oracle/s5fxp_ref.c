@@ -214,8 +214,10 @@ static int mul_cb(const int32_t *x, int xb, int xe, const int32_t *y, int yb, in
 /* ---------------------------------------------------------------- SSM (fxpmodel.py:610-794) */
 static inline int32_t shiftto(int32_t v, int e, int e2) { return e > e2 ? w_asr(v, e - e2) : w_shl(v, e2 - e); }
 
+/* st: NULL, or this layer's carry [2][B][P] (re plane, im plane): the recurrence starts from it and leaves the state after
+ * the last step there (fxpmodel.py:147-172 has the carry as an explicit argument; recurrent_loop passes zeros, :196-207) */
 static int ssm_forward(const ref_ssm *s, const int32_t *xin, int xb, int xe, int B, int L, int32_t *ys,
-                       ref_layer_trace *tr)
+                       ref_layer_trace *tr, int32_t *st)
 {
     const int H = s->H, P = s->P;
     const int64_t N = (int64_t)B * L;
@@ -250,7 +252,7 @@ static int ssm_forward(const ref_ssm *s, const int32_t *xin, int xb, int xe, int
         }
         /* sequential recurrence, no clip (fxpmodel.py:147-172) */
         for (int p = 0; p < P; ++p) {
-            int32_t sr = 0, si = 0, Ar = s->a_re[p], Ai = s->a_im[p];
+            int32_t sr = st ? st[(size_t)b * P + p] : 0, si = st ? st[((size_t)B + b) * P + p] : 0, Ar = s->a_re[p], Ai = s->a_im[p];
             for (int t = 0; t < L; ++t) {
                 int32_t nr = w_add(w_sub(w_asr(w_mul(Ar, sr), s->a_re_exp), w_asr(w_mul(Ai, si), s->a_re_exp)),
                                    shiftto(bur[(size_t)t * P + p], s->bu_re_exp, s->x_re_exp));
@@ -260,6 +262,10 @@ static int ssm_forward(const ref_ssm *s, const int32_t *xin, int xb, int xe, int
                 si = ni;
                 xr[(size_t)t * P + p] = sr;
                 xi[(size_t)t * P + p] = si;
+            }
+            if (st) {
+                st[(size_t)b * P + p] = sr;
+                st[((size_t)B + b) * P + p] = si;
             }
         }
         if (tr) {
@@ -318,8 +324,18 @@ static inline int32_t sigmoid_lut(int32_t x, int xb, int xe, int sx, int sy, con
 }
 
 /* ---------------------------------------------------------------- whole model */
+/* state: NULL, or [n_layers][2][B][P] int32, read and replaced (the streaming carry) */
+int ref_forward_state(const ref_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, int *y_bits,
+                      int *y_exp, ref_layer_trace *traces, int nthreads, int32_t *state);
+
 int ref_forward(const ref_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, int *y_bits,
                 int *y_exp, ref_layer_trace *traces, int nthreads)
+{
+    return ref_forward_state(m, x, x_bits, x_exp, B, L, y, y_bits, y_exp, traces, nthreads, NULL);
+}
+
+int ref_forward_state(const ref_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, int *y_bits,
+                      int *y_exp, ref_layer_trace *traces, int nthreads, int32_t *state)
 {
     if (!m || !x || !y || B <= 0 || L <= 0) return REF_BADARG;
 #ifdef _OPENMP
@@ -363,7 +379,7 @@ int ref_forward(const ref_model *m, const int32_t *x, int x_bits, int x_exp, int
             tr->pre_s5_exp = e2;
             if (tr->pre_s5) memcpy(tr->pre_s5, cur, sz);
         }
-        rc = ssm_forward(&l->ssm, cur, b2, e2, B, L, ysb, tr);
+        rc = ssm_forward(&l->ssm, cur, b2, e2, B, L, ysb, tr, state ? state + (size_t)li * 2 * B * l->ssm.P : NULL);
         if (rc) goto out;
         if (tr && tr->ys) memcpy(tr->ys, ysb, sz);
         /* x1 = relu(y); g = sigmoid(out2(x1)); z = gate(x1, g)  (fxpmodel.py:1125-1137) */

@@ -561,6 +561,8 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
+    const int32_t *state_in = opts ? opts->state_in : nullptr;
+    int32_t *state_out = opts ? opts->state_out : nullptr;
     const WsLayout w = ws_layout(m, B, L);
     if (workspace_bytes < w.total) return S5FXP_EWORKSPACE;
     hipStream_t st = S(stream);
@@ -649,6 +651,9 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         ScanArgs sl{};
         sl.bu_re = I(w.bq); sl.a_re = l.a_re; sl.a_im = l.a_im; sl.out_re = I(w.xs);
         sl.B = B; sl.L = L; sl.P = P; sl.TB = w.TB; sl.ea_re = s.A_re_exp; sl.ea_im = s.A_im_exp;
+        const size_t plane = (size_t)B * P;
+        sl.x0_re = state_in ? state_in + (size_t)li * 2 * plane : nullptr;
+        sl.x0_im = state_in ? sl.x0_re + plane : nullptr;
         const unsigned lane_grid = (unsigned)(((int64_t)B * P + 63) / 64);
         int32_t xmax = (1 << 23) - 1; // the 24-bit C projection's own limit
         const bool quad = l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC);
@@ -656,7 +661,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         if (quad) {
             ScanQuadArgs q{};
             q.bq = I(w.bq); q.xs = I(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = sl.x0_re; q.x0_im = sl.x0_im;
             hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
             xmax = l.quad_xmax;
         } else {
@@ -680,6 +685,10 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
                 hipLaunchKernelGGL(k_scan_lane_native, dim3(lane_grid), dim3(64), 0, st, sl);
             }
             S5_DISPATCH_MW_C(a.mw, false, 1, int32_t, tiles, st, a);
+            if (state_out) // the raw states are still in the stream (either pass): carry out = state after frame L-1
+                hipLaunchKernelGGL(k_state_out, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const void *)I(w.xs), 0,
+                                   (const int32_t *)nullptr, B, L, P, w.TB, state_out + (size_t)li * 2 * plane,
+                                   state_out + (size_t)li * 2 * plane + plane);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);

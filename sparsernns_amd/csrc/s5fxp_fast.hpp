@@ -246,6 +246,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
+    const int32_t *state_in = opts ? opts->state_in : nullptr;
+    int32_t *state_out = opts ? opts->state_out : nullptr;
     const bool exact = opts && (opts->flags & S5FXP_FWD_EXACT);
     const bool defer = opts && (opts->flags & S5FXP_FWD_DEFER_REDO) && !exact;
     const FastWs w = fast_ws(m, B, L);
@@ -446,6 +448,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             }
         }
         // ---- recurrence
+        const size_t plane = (size_t)B * P;
+        const int32_t *x0_re = state_in ? state_in + (size_t)li * 2 * plane : nullptr, *x0_im = state_in ? x0_re + plane : nullptr;
         int32_t xmax = 32767; // the C projection's 16-bit planes
         const bool piped = quad && n_chunks > 1;
         hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
@@ -454,7 +458,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (pairl) {
             ScanPairLArgs q{};
             q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             // one helper wave: a second one lands on the computing wave's half of the CU's LDS store path and costs more
             // than it helps (tools/ubench_pair: 44.2 vs 42.8 us); S5FXP_PAIRL_HELPERS2=1 keeps the variant reachable
             static const bool two_helpers = std::getenv("S5FXP_PAIRL_HELPERS2") != nullptr;
@@ -464,13 +468,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         } else if (pair) {
             ScanPairArgs q{};
             q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             hipLaunchKernelGGL(k_scan_pair_asm, dim3((unsigned)((int64_t)B * (P / 32))), dim3(64), 0, sst, q);
             xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax; // <= 32766: a saturated int16 state fails the check
         } else if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             for (int k = 0; k < (piped ? n_chunks : 1); ++k) {
                 if (piped) {
                     if (k > 0 && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[k], 0)))) return rc;
@@ -487,7 +491,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // states of any width: the exact 32-bit chain in the same quad layout
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = nullptr;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = nullptr; q.x0_re = x0_re; q.x0_im = x0_im;
             hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
         }
         if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], sst)))) return rc;
@@ -565,7 +569,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 if (quad) {
                     ScanQuadArgs q{};
                     q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
-                    q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = &d->redo;
+                    q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = &d->redo; q.x0_re = x0_re; q.x0_im = x0_im;
                     hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
                 }
                 // the exact gate kernel: four byte planes of the int32 states, no range assumption; its maxima go to
@@ -584,6 +588,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     else launch6g(k_cgate_p<2, 3, false, false, false, 64, true>, cgw, smem_w, e);
                 }
             }
+            if (state_out) // carry out: the state after frame L-1, from whichever kernel wrote the stream last
+                hipLaunchKernelGGL(k_state_out, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const void *)I32(w.xs),
+                                   pair ? 2 : (s16 ? 1 : 0), defer ? (const int32_t *)nullptr : (const int32_t *)&d->redo, B, L, P,
+                                   w.TB, state_out + (size_t)li * 2 * plane, state_out + (size_t)li * 2 * plane + plane);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);

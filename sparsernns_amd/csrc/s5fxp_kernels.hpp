@@ -460,6 +460,7 @@ struct ScanArgs {
     int32_t sh_re, sh_im; // Bu exponent - x exponent: > 0 right shift, <= 0 left shift (fxpmodel.py:158-167)
     int32_t relu;
     const int32_t *run_if; // native fallback: run only when *run_if != 0 (nullptr: always)
+    const int32_t *x0_re, *x0_im; // native: (B,P) state before the first step (streaming carry), nullptr = zeros
 };
 
 __device__ __forceinline__ void scan_step(int32_t Ar, int32_t Ai, int ea_re, int ea_im, int32_t br, int32_t bi,
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(64) void k_scan_lane_native(ScanArgs a)
     const int b = (int)(gid / a.P), p = (int)(gid % a.P);
     const int32_t Ar = a.a_re[p], Ai = a.a_im[p];
     const int nblk = (a.L + 3) >> 2;
-    int32_t xr = 0, xi = 0;
+    int32_t xr = a.x0_re ? a.x0_re[gid] : 0, xi = a.x0_re ? a.x0_im[gid] : 0;
     for (int tb = 0; tb < nblk; ++tb) {
         const int64_t w = native_word(b, tb << 2, p, 0, a.TB, a.P);
         const int4 vr = *reinterpret_cast<const int4 *>(a.bu_re + w);

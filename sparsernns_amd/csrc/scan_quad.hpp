@@ -51,7 +51,15 @@ struct ScanQuadArgs {
     int32_t ea_re, ea_im;
     int32_t tb0, ntb;           // k_scan_quad_asm: first time block and block count of this launch (0, 0 = all)
     const int32_t *run_if;      // k_scan_quad32_asm: do the work only when *run_if != 0 (nullptr: always)
+    const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
 };
+
+// the state a quad lane holds before an even step: lanes 0,3 the real part, lanes 1,2 the imaginary part
+__device__ __forceinline__ int32_t quad_x0(const ScanQuadArgs &a, int b, int p, int r)
+{
+    if (!a.x0_re) return 0;
+    return (r == 0 || r == 3) ? a.x0_re[(size_t)b * a.P + p] : a.x0_im[(size_t)b * a.P + p];
+}
 
 // PRE is "s_nop 1\n\t" for the first step after a 16-byte buffer_store: gfx940+ needs 2 wait states
 // between such a store and a VALU write to one of its data registers, and hipcc pads nothing
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
     // bproj | scan | cgate pipeline starts from the last state of the previous chunk.  After an odd step lanes
     // 0,3 of a quad hold the real part and lanes 1,2 the imaginary part.
     const int tb0 = a.tb0, ntb = a.ntb > 0 ? a.ntb : a.TB - a.tb0;
-    int32_t x0 = 0;
+    int32_t x0 = quad_x0(a, b, p, r);
     if (tb0 > 0) x0 = a.xs[native_word(b, 4 * tb0 - 1, p, (r == 0 || r == 3) ? 0 : 1, a.TB, a.P)];
     const size_t wave_off = (((size_t)b * a.TB + tb0) * a.P + p0) * 8; // words
     const unsigned blk_stride = (unsigned)a.P * 32u;
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a)
     else if (r == 1) { cA = cB = Ar << sim; }
     else if (r == 2) { cA = -(Ai << sre); kA = kre; cB = Ai << sim; }
     else { cA = Ai << sim; cB = -(Ai << sre); kB = kre; }
-    const int32_t x0 = 0;
+    const int32_t x0 = quad_x0(a, b, p, r);
     const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // halfwords
     const unsigned blk_stride = (unsigned)a.P * 16u;
     const unsigned extent = (unsigned)a.TB * blk_stride;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(64) void k_scan_quad32_asm(ScanQuadArgs a)
     else if (r == 1) { cA = cB = Ar; sA = sB = a.ea_im; }
     else if (r == 2) { cA = cB = Ai; sA = a.ea_re; mA = -1; sB = a.ea_im; }
     else { cA = cB = Ai; sA = a.ea_im; sB = a.ea_re; mB = -1; }
-    const int32_t oA = mA & 1, oB = mB & 1, x0 = 0;
+    const int32_t oA = mA & 1, oB = mB & 1, x0 = quad_x0(a, b, p, r);
     const size_t wave_off = (((size_t)b * a.TB) * a.P + p0) * 8; // words
     const unsigned blk_stride = (unsigned)a.P * 32u;
     const unsigned extent = (unsigned)a.TB * blk_stride;
@@ -274,12 +282,44 @@ __device__ __forceinline__ int64_t pair_word(int64_t b, int tb, int p, int TB, i
     return ((((b * (P >> 5) + (p >> 5)) * TB + tb) << 5) + (p & 31)) << 3;
 }
 
+// The state after step L-1 of every (sequence, state), read back from the stream the recurrence wrote (the streaming
+// carry out).  mode 0: scan-native int32, 1: scan-native int16, 2: pair-native int16.  With redo != nullptr and *redo
+// != 0 the exact re-run has rewritten the stream as scan-native int32 (mode 0) whatever the fast kernel's mode was.
+__global__ void k_state_out(const void *xs, int mode, const int32_t *redo, int B, int L, int P, int TB, int32_t *out_re,
+                            int32_t *out_im)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * P) return;
+    const int b = i / P, p = i % P, t = L - 1;
+    if (redo && *redo) mode = 0;
+    int32_t re, im;
+    if (mode == 0) {
+        const int32_t *x = reinterpret_cast<const int32_t *>(xs);
+        re = x[native_word(b, t, p, 0, TB, P)];
+        im = x[native_word(b, t, p, 1, TB, P)];
+    } else if (mode == 1) {
+        const int16_t *x = reinterpret_cast<const int16_t *>(xs);
+        re = x[native_word(b, t, p, 0, TB, P)];
+        im = x[native_word(b, t, p, 1, TB, P)];
+    } else {
+        const int16_t *x = reinterpret_cast<const int16_t *>(xs) + (pair_word(b, t >> 3, p, TB >> 1, P) << 1);
+        const int j = t & 7, jj = j & 3;
+        const int hw = (2 * (j >> 2) + (jj & 1)) * 2 + (jj >> 1); // position of step j in a lane's 8-step item
+        const int16_t va = x[hw], vb = x[8 + hw];                  // lane A, lane B
+        re = (j & 1) ? va : vb;                                    // even steps: lane A computed im, lane B re
+        im = (j & 1) ? vb : va;
+    }
+    out_re[i] = re;
+    out_im[i] = im;
+}
+
 struct ScanPairArgs {
     const int32_t *k;           // pair-native K stream
     int16_t *xs;                // pair-native packed states
     const int32_t *a_re, *a_im; // (P)
     int32_t B, TB, P;           // TB % S5_SCANP_ASM_DEPTH == 0
     int32_t ea_re, ea_im;
+    const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
 };
 
 __global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
@@ -298,7 +338,9 @@ __global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
     const unsigned long long pin = (unsigned long long)(a.k + (size_t)wave * a.TB * 256),
                              pout = (unsigned long long)(a.xs + (size_t)wave * a.TB * 256);
     const unsigned vin = lane * 16 + 4096, vout = vin;
-    const int32_t x0 = 0;
+    // lane A holds re before an even step, lane B im
+    const size_t sp = (size_t)(wave / (a.P >> 5)) * a.P + p;
+    const int32_t x0 = a.x0_re ? (laneB ? a.x0_im[sp] : a.x0_re[sp]) : 0;
     unsigned cnt = (unsigned)a.TB / S5_SCANP_ASM_DEPTH;
     asm volatile(S5_SCANP_ASM_BODY
                  : [cnt] "+s"(cnt)
@@ -328,6 +370,7 @@ struct ScanPairLArgs {
     int32_t B, TB, P;           // TB % S5_SCANPL_BLOCKS == 0
     int32_t ea_re, ea_im;
     int32_t dbg;                // tools/ubench_pair.hip only: 1 = the helper skips its loads, 2 = it only meets the barriers
+    const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
 };
 
 template <int NHELP> // helper waves per workgroup (1 or 2): each expands an equal share of every iteration's blocks
@@ -432,7 +475,9 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void k_scan_pairl_asm(ScanPairLAr
     const int32_t coo = laneB ? c_im_own : c_re_own, cpo = laneB ? c_im_part : c_re_part;
     const unsigned long long pout = (unsigned long long)(a.xs + (size_t)wave * a.TB * 256);
     const unsigned vlds = (unsigned)(size_t)kbuf + lane * 16, vout = lane * 16 + 4096;
-    const int32_t x0 = 0;
+    const size_t sp = (size_t)(wave / (a.P >> 5)) * a.P + p;
+    const int32_t x0 = a.x0_re ? (laneB ? a.x0_im[sp] : a.x0_re[sp]) : 0; // lane A holds re before an even step
+
     unsigned cnt = (unsigned)n_it;
     asm volatile(S5_SCANPL_ASM_BODY
                  : [cnt] "+s"(cnt)

@@ -137,7 +137,8 @@ class Engine:
 
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
                 traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
-                scan_events: Optional[list] = None, flags: int = 0, lane: int = 0) -> None:
+                scan_events: Optional[list] = None, flags: int = 0, lane: int = 0,
+                state_in: Optional[torch.Tensor] = None, state_out: Optional[torch.Tensor] = None) -> None:
         """Launches one forward on the current stream; nothing is synchronised.
 
         flags: _lib.FWD_DEFER_REDO drops the (normally idle) gated exact re-run launches -- the caller must then
@@ -171,6 +172,11 @@ class Engine:
             opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
             self._ev_keep = arr
         opts.flags = int(flags)
+        for name, t in (("state_in", state_in), ("state_out", state_out)):
+            if t is not None:
+                if t.dtype != torch.int32 or tuple(t.shape) != (self.n_layers, 2, B, self.P) or not t.is_contiguous() or not t.is_cuda:
+                    raise ValueError(f"{name} must be a contiguous int32 device tensor of shape (n_layers, 2, B, P)")
+                setattr(opts, name, t.data_ptr())
         self._cb_keep = opts
         check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
                                       ws.numel(), self.lane_status(lane).data_ptr(),
@@ -226,6 +232,57 @@ class Engine:
                 self.check_status()
         out = FxpArray(y, self.out_bits, self.out_exp, True)
         return (out, tr) if traces else out
+
+
+    # -- streaming ------------------------------------------------------------------------------
+    def zero_state(self, B: int) -> torch.Tensor:
+        """The carry a sequence starts with: (n_layers, 2, B, P) int32 zeros (re plane, im plane per layer)."""
+        return torch.zeros((self.n_layers, 2, B, self.P), dtype=torch.int32, device=self.device)
+
+    def forward_chunk(self, x: FxpArray, state: Optional[torch.Tensor] = None):
+        """One chunk of a stream: x (B,L,d_in) or (L,d_in); `state` from zero_state() or the previous call (None: zeros).
+        Returns (y, new_state).  What comes out is what the reference computes for THIS chunk when its recurrences
+        (sparseRNNs/fxpmodel.py:147-172, the carry is an explicit argument of the step function) start from `state`;
+        every chunk is its own compute_best batch.  `state` is not modified."""
+        data = x.data.contiguous()
+        if data.shape[-1] != self.d_in:
+            raise ValueError(f"expected last dim {self.d_in}, got {tuple(data.shape)}")
+        B, L = (1, data.shape[0]) if data.ndim == 2 else (data.shape[0], data.shape[1])
+        if B * L == 0:
+            raise ValueError("empty chunk")
+        y = torch.empty(tuple(data.shape[:-1]) + (self.d_out,), dtype=torch.int32, device=data.device)
+        new_state = torch.empty((self.n_layers, 2, B, self.P), dtype=torch.int32, device=data.device)
+        first = _lib.FWD_EXACT if self.redo_seen >= 2 else _lib.FWD_DEFER_REDO
+        self.enqueue(data, x.bits, x.exp, y, B, L, flags=first, state_in=state, state_out=new_state)
+        st = self.check_status()
+        if st[0] & _lib.ST_REDO:  # `state` is untouched: repeat the chunk with the exact kernels
+            self.redo_seen += 1
+            self.enqueue(data, x.bits, x.exp, y, B, L, flags=_lib.FWD_EXACT, state_in=state, state_out=new_state)
+            self.check_status()
+        return FxpArray(y, self.out_bits, self.out_exp, True), new_state
+
+    def stream(self, B: int = 1) -> "StreamingSession":
+        return StreamingSession(self, B)
+
+
+class StreamingSession:
+    """Frame-chunk-at-a-time inference with the SSM states carried between calls (the paper's
+    real-time denoising use).  ``push`` takes (B,L,d_in) / (L,d_in) chunks of any length and returns the outputs of
+    exactly those frames."""
+
+    def __init__(self, engine: "Engine", B: int = 1):
+        self.engine, self.B = engine, B
+        self.state = engine.zero_state(B)
+        self.frames = 0
+
+    def push(self, x: FxpArray) -> FxpArray:
+        y, self.state = self.engine.forward_chunk(x, self.state)
+        self.frames += x.data.shape[-2]
+        return y
+
+    def reset(self) -> None:
+        self.state = self.engine.zero_state(self.B)
+        self.frames = 0
 
 
 class InflightRunner:

@@ -406,3 +406,24 @@ def test_config0_float_forward_plumbing_and_fixed_point_tracks_it():
     err = np.abs(yq - yf).max() / (np.abs(yf).max() + 1e-12)
     corr = np.corrcoef(yq.ravel(), yf.ravel())[0, 1]
     assert corr > 0.5 and err < 2.0, (corr, err)
+
+
+def test_streaming_carry_in_both_oracle_halves():
+    """The streaming carry (fxpmodel.py:147-172: the step function's state is an explicit argument): NumPy half == C half
+    chunk by chunk, carries equal after every chunk, and a zero carry is the plain forward."""
+    md, qc, dims = synth.make_model(dims=synth.tiny_dims(H=12, P=6, d_in=7, d_out=9, n_layers=2), bn_scale_bias=True, input_scale=30.0)
+    m = O.RegressionModel(md, qc, dims["n_layers"])
+    cm = cref.CModel(m.export())
+    B = 3
+    st = m.zero_state((B,))
+    stc = np.zeros((dims["n_layers"], 2, B, dims["P"]), dtype=np.int32)
+    for i, L in enumerate((16, 1, 23, 40)):
+        x = synth.make_input(B, L, dims["d_in"], seed=50 + i, scale=30.0)
+        fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+        a = m(fx, None, st).data
+        b = cm.forward(fx.data, fx.bits, fx.exp, state=stc)[0]
+        assert np.array_equal(a, b), i
+        assert all(np.array_equal(st[l][c], stc[l, c]) for l in range(dims["n_layers"]) for c in range(2)), i
+        if i == 0:
+            assert np.array_equal(a, m(fx).data)  # zero carry
+    assert np.abs(stc).max() > 0

@@ -780,3 +780,40 @@ def test_pair_recurrence_kernel_is_selected_and_guarded():
         r = subprocess.run([sys.executable, "-c", code2], cwd=root, capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, **{var: "1"}))
         assert r.returncode == 0 and "pair variant ok" in r.stdout, var + r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("engine_flags", [0, "generic"])
+def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
+    """SURVEY.md 8(f)4 / fxpmodel.py:147-172: a sequence fed chunk by chunk with the SSM states carried between calls.
+    Per chunk the GPU must give what the oracle gives for that chunk started from the same carry (both oracle halves
+    agree on that in the CPU suite), the carry itself must match after every chunk, chunk lengths are ragged, one chunk
+    overflows the fast recurrence's range (exact repeat from the untouched carry), and a carry of zeros is the plain
+    forward."""
+    import torch
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5, calib_L=256))
+    flags = _lib.MODEL_FORCE_GENERIC if engine_flags == "generic" else 0
+    model = build_regression_model(md, qc, dims["n_layers"], engine_flags=flags)
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    B = 2
+    sess = eng.stream(B)
+    ref_state = np.zeros((dims["n_layers"], 2, B, dims["P"]), dtype=np.int32)
+    lens = (64, 128, 36, 4, 200) if engine_flags == 0 else (64, 37, 5)   # the MFMA path needs L % 4 == 0
+    for i, L in enumerate(lens):
+        fx = _input(qc, dims, B, L, seed=300 + i, scale=6.0 if i == 2 else 1.0)
+        ref, rb, re_, _ = cm.forward(fx.data, fx.bits, fx.exp, state=ref_state)   # updates ref_state in place
+        y = sess.push(FxpArray(fx.data, fx.bits, fx.exp))
+        assert (y.bits, y.exp) == (rb, re_)
+        assert np.array_equal(y.numpy(), ref), f"chunk {i} (L={L})"
+        assert np.array_equal(sess.state.cpu().numpy(), ref_state), f"carry after chunk {i}"
+    assert sess.frames == sum(lens) and np.abs(ref_state).max() > 0
+    # zero carry == the stateless forward
+    fx = _input(qc, dims, B, 64, seed=9)
+    y0, st = eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), None)
+    assert np.array_equal(y0.numpy(), eng.forward(FxpArray(fx.data, fx.bits, fx.exp)).numpy())
+    with pytest.raises(ValueError):
+        eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), torch.zeros((1, 2, B, dims["P"]), dtype=torch.int32, device="cuda"))
