@@ -11,6 +11,10 @@ replaced by interchange files this repo can read:
                          npz, ``export_qconfig`` in the json: the format of tests/golden/*.npz); a maintainer
                          with JAX writes it from the reference with
                          ``np.savez(path, **{f"params/{k}": v for k, v in flatten(model.export()["params"])})``
+  --params P.npz --stats S.npz [--separate_exponents]
+                         the reference's calibration output (``sc_calibrated_params.pkl`` / ``sc_cal_stats.pkl``) as npz
+                         trees: modeldict and fxp_qconfig are derived exactly as
+                         ``fxprun.py:294-397`` derives them (sparsernns_amd/fxputils.py), then the model is built from them
   --inputs X.npy         float32 (B,L,d_in) model inputs (the reference's ``inputs.npy``); default: synthetic
 
 Flags kept from the reference where they mean the same: --quantization, --seq_len, --bsz, --export.
@@ -62,6 +66,9 @@ def main(argv=None) -> int:
     src = ap.add_mutually_exclusive_group(required=True)
     src.add_argument("--synthetic", action="store_true")
     src.add_argument("--model", type=str, help="integer model, export() layout (.npz)")
+    src.add_argument("--params", type=str, help="calibrated float parameters as an npz tree (needs --stats)")
+    ap.add_argument("--stats", type=str, help="calibration statistics as an npz tree (with --params)")
+    ap.add_argument("--separate_exponents", action="store_true", help="per-layer exponents, as the reference's flag (with --params)")
     ap.add_argument("--meta", type=str, help="json beside --model (export_qconfig, input bits/exp)")
     ap.add_argument("--inputs", type=str, default=None, help="float32 (B,L,d_in) .npy")
     ap.add_argument("--outputs", type=str, default=None, help="write the float outputs here (.npy)")
@@ -92,7 +99,17 @@ def main(argv=None) -> int:
     from .fxpmodel import build_regression_model
 
     model = None
-    if args.synthetic:
+    if args.params:
+        if not args.stats:
+            ap.error("--params needs --stats")
+        from . import fxputils
+        md, qc = fxputils.derive(fxputils.load_tree_npz(args.params), fxputils.load_tree_npz(args.stats), args.quantization,
+                                 separate_exponents=args.separate_exponents)
+        dims = dict(n_layers=len([k for k in md["encoder"] if k.startswith("layers_")]))
+        model = build_regression_model(md, qc, dims["n_layers"])
+        eng = model.engine()
+        inp_bits, inp_exp, d_in = int(qc["encoder"]["inp_bits"]), int(qc["encoder"]["inp_exp"]), eng.d_in
+    elif args.synthetic:
         md, qc, dims = synth.make_model(args.dim_scale, quantization=args.quantization, sparsity=args.sparsity,
                                         calib_L=min(1024, max(64, args.seq_len)), state_headroom_bits=1)
         model = build_regression_model(md, qc, dims["n_layers"])

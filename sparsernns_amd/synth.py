@@ -215,10 +215,12 @@ def fracbits_from_absmax(absmax: float, bits: int) -> int:
     return -int(round(math.log2(absmax / float((1 << (bits - 1)) - 1))))
 
 
-def _entry(absmax: float, bits: int, full_range: bool = False) -> dict:
-    absmax = max(float(absmax), 1e-12)
-    ib, fb = get_intbits(absmax), fracbits_from_absmax(absmax, bits)
-    return dict(absmax=absmax, intbits=ib, signbits=1, fracbits=fb, bits=bits, exp=fb if full_range else min(fb, bits - 1 - ib))
+def _entry(absmax, bits: int, full_range: bool = False) -> dict:
+    """absmax: one value, or one per layer.  Shared exponents take the maximum over layers of EVERY field separately
+    (fxputils.py:288-348): the largest intbits and the largest fracbits, which need not come from the same layer."""
+    vals = [max(float(a), 1e-12) for a in (absmax if isinstance(absmax, (list, tuple)) else [absmax])]
+    ib, fb = max(get_intbits(a) for a in vals), max(fracbits_from_absmax(a, bits) for a in vals)
+    return dict(absmax=max(vals), intbits=ib, signbits=1, fracbits=fb, bits=bits, exp=fb if full_range else min(fb, bits - 1 - ib))
 
 
 def derive_qconfig(modeldict: dict, stats: dict, n_layers: int, precisions: dict = W8A16) -> dict:
@@ -233,26 +235,27 @@ def derive_qconfig(modeldict: dict, stats: dict, n_layers: int, precisions: dict
         return globals()["_entry"](absmax, bits, full)
 
     def dense_cfg(dense_list, inp_absmax, out_absmax):
-        w = _entry(max(np.abs(d["kernel"]).max() for d in dense_list), wb)
+        w = _entry([np.abs(d["kernel"]).max() for d in dense_list], wb)
         inp, out = _entry(inp_absmax, ab), _entry(out_absmax, ab)
-        b = _entry(max(np.abs(d["bias"]).max() for d in dense_list), bb)
-        b["exp"] = min(inp["fracbits"], bb - 1 - b["intbits"])  # bias fracbits come from act_scale, fxputils.py:266
+        b = _entry([np.abs(d["bias"]).max() for d in dense_list], bb)
+        b["fracbits"] = inp["fracbits"]  # the bias shares the input's scale (act_scale), fxputils.py:266
+        b["exp"] = b["fracbits"] if full else min(b["fracbits"], bb - 1 - b["intbits"])
         cfg = {}
         for p, e in (("w", w), ("b", b), ("inp", inp), ("out", out)):
             cfg.update({f"{p}_bits": e["bits"], f"{p}_exp": e["exp"], f"{p}_absmax": e["absmax"],
                         f"{p}_intbits": e["intbits"], f"{p}_fracbits": e["fracbits"], f"{p}_signbit": 1})
         return cfg
 
-    lmax = lambda key: max(stats[f"l{i}.{key}"] for i in range(n_layers))
+    lmax = lambda key: [stats[f"l{i}.{key}"] for i in range(n_layers)]  # one value per layer
     zs = [zoh(l["mixer"]) for l in layers]
     wts = dict(
-        A_re=_entry(max(np.abs(z[0].real).max() for z in zs), sa),  # fxputils.py:557-562: Lambda gets act bits
-        A_im=_entry(max(np.abs(z[0].imag).max() for z in zs), sa),
-        B_re=_entry(max(np.abs(z[1].real).max() for z in zs), sw),
-        B_im=_entry(max(np.abs(z[1].imag).max() for z in zs), sw),
-        C_re=_entry(max(np.abs(z[2].real).max() for z in zs), sw),
-        C_im=_entry(max(np.abs(z[2].imag).max() for z in zs), sw),
-        D=_entry(max(np.abs(l["mixer"]["D"]).max() for l in layers), sw))
+        A_re=_entry([np.abs(z[0].real).max() for z in zs], sa),  # fxputils.py:557-562: Lambda gets act bits
+        A_im=_entry([np.abs(z[0].imag).max() for z in zs], sa),
+        B_re=_entry([np.abs(z[1].real).max() for z in zs], sw),
+        B_im=_entry([np.abs(z[1].imag).max() for z in zs], sw),
+        C_re=_entry([np.abs(z[2].real).max() for z in zs], sw),
+        C_im=_entry([np.abs(z[2].imag).max() for z in zs], sw),
+        D=_entry([np.abs(l["mixer"]["D"]).max() for l in layers], sw))
     acts = {k: _entry(lmax(k), sa) for k in ["u", "Bu_re", "Bu_im", "x_re", "x_im", "y"]}
     gl, gr = _entry(lmax("gate.l"), ab), _entry(lmax("gate.r"), ab)
     multgate = dict(l_bits=ab, l_exp=gl["exp"], r_bits=ab, r_exp=gr["exp"], res_bits=ab,
@@ -351,3 +354,47 @@ def _assert_exps_nonnegative(tree, path="fxp_qconfig"):
 def tiny_dims(H: int = 8, P: int = 4, d_in: int = 5, d_out: int = 5, n_layers: int = 2) -> dict:
     """Small shapes for fixtures: P must be blocks * block_size/2 with an even block_size."""
     return dict(H=H, P=P, blocks=P // 2, block_size=4, n_layers=n_layers, d_in=d_in, d_out=d_out)
+
+
+# --------------------------------------------------------------------------------------
+# the same calibration result in the reference's checkpoint layout (what convert.py leaves behind)
+# --------------------------------------------------------------------------------------
+def reference_trees(modeldict: dict, stats: dict, n_layers: int, precisions: dict = W8A16) -> Tuple[dict, dict]:
+    """(params, stats) trees shaped like ``sc_calibrated_params.pkl`` / ``sc_cal_stats.pkl``:
+    float parameters on one side; on the other, per observed tensor, the calibrated power-of-two ``scale``
+    (utils/quantization.py:352-370) and an ``observer`` with its min / max.  ``sparsernns_amd.fxputils.derive`` turns
+    them back into (modeldict, fxp_qconfig); the CPU suite checks that this reproduces ``derive_qconfig``."""
+    wb, ab = precisions["non_ssm_w"], precisions["non_ssm_act"]
+    sw, sa = precisions["ssm_w"], precisions["ssm_act"]
+
+    def pow2_scale(absmax, bits):
+        return F32(2.0 ** round(math.log2(max(float(absmax), 1e-12) / float((1 << (bits - 1)) - 1))))
+
+    def observed(absmax, bits, stem=""):
+        a = F32(max(float(absmax), 1e-12))
+        return dict(scale=pow2_scale(a, bits), observer={f"{stem}observer_min": -a, f"{stem}observer_max": a})
+
+    def dense_stats(d, inp_absmax, out_absmax):
+        a_in, a_out = F32(max(float(inp_absmax), 1e-12)), F32(max(float(out_absmax), 1e-12))
+        return dict(act_scale=pow2_scale(a_in, ab), weight_scale=pow2_scale(np.abs(d["kernel"]).max(), wb),
+                    out_scale=pow2_scale(a_out, ab),
+                    input_observer=dict(input_observer_min=-a_in, input_observer_max=a_in),
+                    output_observer=dict(output_observer_min=-a_out, output_observer_max=a_out))
+
+    enc = modeldict["encoder"]
+    params = dict(encoder=dict(encoder=dict(enc["encoder"])), decoder=dict(modeldict["decoder"]))
+    st = dict(encoder=dict(encoder=dense_stats(enc["encoder"], stats["encoder.inp"], stats["encoder.out"])),
+              decoder=dense_stats(modeldict["decoder"], stats["decoder.inp"], stats["decoder.out"]))
+    for i in range(n_layers):
+        layer = enc[f"layers_{i}"]
+        lam_bar, B_bar, C = zoh(layer["mixer"])
+        cplx = lambda z, bits: dict(quant_real=observed(np.abs(z.real).max(), bits), quant_imag=observed(np.abs(z.imag).max(), bits))
+        act2 = lambda k: dict(quant_real=observed(stats[f"l{i}.{k}_re"], sa), quant_imag=observed(stats[f"l{i}.{k}_im"], sa))
+        params["encoder"][f"layers_{i}"] = dict(norm=dict(layer["norm"]), mixer=dict(layer["mixer"]), out2=dict(layer["out2"]))
+        st["encoder"][f"layers_{i}"] = dict(
+            mixer=dict(quant_A=cplx(lam_bar, sa), quant_B=cplx(B_bar, sw), quant_C=cplx(C, sw),
+                       quant_D=observed(np.abs(layer["mixer"]["D"]).max(), sw), quant_ut=observed(stats[f"l{i}.u"], sa),
+                       quant_But=act2("Bu"), quant_xt=act2("x"), quant_yt=observed(stats[f"l{i}.y"], sa)),
+            mult_gate=dict(quant_left=observed(stats[f"l{i}.gate.l"], ab), quant_right=observed(stats[f"l{i}.gate.r"], ab)),
+            out2=dense_stats(layer["out2"], stats[f"l{i}.out2.inp"], stats[f"l{i}.out2.out"]))
+    return params, st

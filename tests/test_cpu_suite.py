@@ -427,3 +427,88 @@ def test_streaming_carry_in_both_oracle_halves():
         if i == 0:
             assert np.array_equal(a, m(fx).data)  # zero carry
     assert np.abs(stc).max() > 0
+
+
+# ------------------------------------------------------------------------------------------
+# qconfig derivation from calibration trees (sparsernns_amd/fxputils.py <- sparseRNNs/fxputils.py:121-134,351-401,453-786)
+# ------------------------------------------------------------------------------------------
+def _calibrated(dim_scale=0.5, bn_scale_bias=False, seed=1919):
+    dims = synth.ndns_dims(dim_scale)
+    md = synth.make_float_params(dims, seed, bn_scale_bias)
+    stats = {}
+    synth.float_forward(md, synth.make_input(2, 128, dims["d_in"], seed=seed + 1), dims["n_layers"], calibrate_bn=True, stats=stats)
+    return md, stats, dims
+
+
+def _same_numbers(a, b, path=""):
+    """every bits / exp / intbits / fracbits / absmax of `a` is in `b` with the same value"""
+    n = 0
+    for k, v in a.items():
+        if isinstance(v, dict):
+            n += _same_numbers(v, b[k], f"{path}/{k}")
+        elif k.endswith(("bits", "exp", "intbits", "fracbits")):
+            assert b[k] == v, (path, k, v, b[k])
+            n += 1
+        elif k.endswith("absmax"):
+            assert abs(b[k] - v) <= 1e-6 * abs(v), (path, k, v, b[k])
+            n += 1
+    return n
+
+
+def test_fxputils_reproduces_the_synthetic_qconfig_from_checkpoint_shaped_trees(tmp_path):
+    from sparsernns_amd import fxputils
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, stats, dims = _calibrated()
+    want = synth.derive_qconfig(md, stats, dims["n_layers"])
+    params, st = synth.reference_trees(md, stats, dims["n_layers"])
+    # the interchange format: one npz per tree, '/'-joined paths, no pickles
+    fxputils.save_tree_npz(tmp_path / "params.npz", params)
+    fxputils.save_tree_npz(tmp_path / "stats.npz", st)
+    params2, st2 = fxputils.load_tree_npz(tmp_path / "params.npz"), fxputils.load_tree_npz(tmp_path / "stats.npz")
+    md2, qc = fxputils.derive(params2, st2, "w8a16")
+    assert _same_numbers(want, qc) > 150
+    assert fxputils.precisions_for("w8a16") == synth.W8A16 and fxputils.precisions_for("w8a8") == synth.W8A8
+    # load_modeldict's marks: every *scale* leaf is a log2 now, every observer has absmax / intbits
+    d = md2["encoder"]["encoder"]
+    assert float(d["act_scale"]) == round(float(d["act_scale"])) and d["input_observer"]["intbits"] == int(np.ceil(np.log2(d["input_observer"]["absmax"])))
+    # the derived pair builds the same integer model as the synthetic pair (oracle and product setup)
+    a = O.RegressionModel(md, want, dims["n_layers"]).export()
+    b = O.RegressionModel(md2, qc, dims["n_layers"]).export()
+    tree_equal(a["params"], b["params"], "params")
+    tree_equal(build_regression_model(md2, qc, dims["n_layers"]).export()["params"], b["params"], "product")
+
+
+def test_fxputils_separate_exponents_and_batchnorm_scale_quirk():
+    from sparsernns_amd import fxputils
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, stats, dims = _calibrated(bn_scale_bias=True, seed=7)
+    md["encoder"]["layers_1"]["norm"]["scale"][3] = -0.7            # log2 of a negative scale is NaN ...
+    params, st = synth.reference_trees(md, stats, dims["n_layers"])
+    md2, qc = fxputils.derive(params, st, "w8a16", separate_exponents=True)
+    assert set(qc["blocks"]) == {"layers_0", "layers_1", "layers_2"}  # --separate_exponents layout (fxputils.py:386-401)
+    sc = md2["encoder"]["layers_1"]["norm"]["scale"]
+    want = np.log2(md["encoder"]["layers_1"]["norm"]["scale"].astype(np.float32), where=md["encoder"]["layers_1"]["norm"]["scale"] > 0,
+                   out=np.ones_like(sc))
+    assert sc[3] == 1.0 and np.allclose(sc, want)                    # ... which the reference replaces by 1.0 (:711-731)
+    for i in range(3):
+        blk = qc["blocks"][f"layers_{i}"]
+        assert set(blk) == {"ssm", "multgate", "out2", "norm"} and set(blk["norm"]) == {"mean", "var", "invsq_var", "scale", "bias"}
+        own = max(0, int(np.ceil(np.log2(np.abs(md["encoder"][f"layers_{i}"]["norm"]["mean"]).max()))))
+        assert blk["norm"]["mean"]["exp"] == 15 - own
+    # per-layer exponents are at least as fine as the shared ones, and the model builds and runs from them
+    shared = fxputils.derive(*synth.reference_trees(md, stats, dims["n_layers"]), "w8a16")[1]
+    for i in range(3):
+        for t, e in qc["blocks"][f"layers_{i}"]["ssm"]["activations"].items():
+            assert e["exp"] >= shared["blocks"]["ssm"]["activations"][t]["exp"], (i, t)
+    x = synth.make_input(1, 24, dims["d_in"], seed=3)
+    fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+    model = O.RegressionModel(md2, qc, dims["n_layers"])
+    y = model(fx)
+    yc = cref.CModel(build_regression_model(md2, qc, dims["n_layers"]).export()).forward(fx.data, fx.bits, fx.exp)[0]
+    assert np.array_equal(y.data, yc)
+    with pytest.raises(ValueError):
+        fxputils.create_fxp_qconfig(md2, agg="mean")
+    full, joined = fxputils.create_fxp_qconfig(fxputils.load_modeldict(*synth.reference_trees(md, stats, dims["n_layers"])), agg="set")
+    assert isinstance(joined["blocks"]["ssm"]["activations"]["u"]["fracbits"], list) and "layers_0" in full["blocks"]["ssm"]

@@ -817,3 +817,32 @@ def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
     assert np.array_equal(y0.numpy(), eng.forward(FxpArray(fx.data, fx.bits, fx.exp)).numpy())
     with pytest.raises(ValueError):
         eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), torch.zeros((1, 2, B, dims["P"]), dtype=torch.int32, device="cuda"))
+
+
+def test_fxprun_cli_from_calibration_trees(tmp_path):
+    """--params / --stats: the reference's calibration output as npz trees -> fxputils.derive -> model -> forward.  The
+    outputs must be those of the model built directly from the same float parameters and statistics, shared and
+    per-layer exponents."""
+    from sparsernns_amd import fxprun, fxputils
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    dims = synth.ndns_dims(0.5)
+    md = synth.make_float_params(dims, 1919)
+    stats = {}
+    synth.float_forward(md, synth.make_input(2, 256, dims["d_in"], seed=1920), dims["n_layers"], calibrate_bn=True, stats=stats)
+    qc = synth.derive_qconfig(md, stats, dims["n_layers"])
+    params, st = synth.reference_trees(md, stats, dims["n_layers"])
+    fxputils.save_tree_npz(tmp_path / "p.npz", params)
+    fxputils.save_tree_npz(tmp_path / "s.npz", st)
+    x = synth.make_input(2, 128, dims["d_in"], seed=8)
+    np.save(tmp_path / "x.npy", x)
+    common = ["--params", str(tmp_path / "p.npz"), "--stats", str(tmp_path / "s.npz"), "--inputs", str(tmp_path / "x.npy"), "--steps", "0"]
+    assert fxprun.main(common + ["--outputs", str(tmp_path / "y.npy")]) == 0
+    fx = O.from_fp(x, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+    want = build_regression_model(md, qc, dims["n_layers"])(FxpArray(fx.data, fx.bits, fx.exp))
+    assert np.array_equal(np.load(tmp_path / "y.npy"), want.to_float().cpu().numpy())
+    assert fxprun.main(common + ["--separate_exponents", "--outputs", str(tmp_path / "y2.npy")]) == 0
+    md2, qc2 = fxputils.derive(params, st, "w8a16", separate_exponents=True)
+    ref = cref.CModel(build_regression_model(md2, qc2, dims["n_layers"]).export()).forward(fx.data, fx.bits, fx.exp)
+    assert np.array_equal(np.load(tmp_path / "y2.npy"), ref[0].astype(np.float32) / (1 << ref[2]))
