@@ -83,6 +83,73 @@ __device__ __forceinline__ void quad_transpose(int32_t (&w)[4], int lane)
     }
 }
 
+// ---- packed 16-bit helpers of the PK16 epilogues (semantics probed on MI355X: tools/probe_pk16.hip -- the clamped forms
+// saturate the EXACT result, v_cvt_pk_i16_i32 saturates each half, the SDWA forms sign-extend the selected half)
+__device__ __forceinline__ uint32_t pk_cvt(int32_t lo, int32_t hi) // (sat16(lo), sat16(hi))
+{
+    uint32_t r;
+    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_sat(uint32_t a, uint32_t m, uint32_t c) // sat16(a * m + c) per half
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(m), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_ashr(uint32_t a, uint32_t s) // s = shift in both halves
+{
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(s), "v"(a));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ int32_t mul24_h(int32_t a, uint32_t pk) // a * sext(half HALF of pk)
+{
+    int32_t r;
+    if (HALF == 0)
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(pk));
+    else
+        asm("v_mul_i32_i24_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(pk));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ float cvtf_h(uint32_t pk) // float(sext(half))
+{
+    float r;
+    if (HALF == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(pk));
+    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(pk));
+    return r;
+}
+template <int HALF>
+__device__ __forceinline__ int32_t ashr_h(int32_t s, uint32_t pk) // sext(half) >> s
+{
+    int32_t r;
+    if (HALF == 0)
+        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(pk));
+    else
+        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(pk));
+    return r;
+}
+
 constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checked)
 constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 
@@ -97,7 +164,10 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // -- all modulo 2^32, which is the reference's int32 matmul (fxparray.py:662).  No range check, complex ReLU through
 // float32 exactly as the reference does it (fxp_prims.hpp crelu).
 // PAIR (with S16): the states come from k_scan_pair_asm in pair-native order (scan_quad.hpp)
-template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false>
+// PK16 (with DIRECT): y, out2 output, the gate's l operand and its result are all 16 bit, no out2 input conversion and
+// every |bias_eff| fits 16 bits (host-checked, s5fxp_fast.hpp): both epilogues run on packed int16 pairs -- saturating
+// packs, clamped packed sub / mad / add, SDWA half-word operands -- about a third fewer VALU instructions, same results
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false, bool PK16 = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
 {
@@ -132,8 +202,12 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
         for (int ks = 0; ks < NT; ++ks) wo2[ks] = *reinterpret_cast<const v4i *>(a.w_o2.wt + row * a.w_o2.Kp + 32 * ks + 16 * h);
     }
     for (int i = threadIdx.x; i < H; i += NTHR) {
-        csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i]; be[i] = a.bias_eff[i];
+        csr[i] = a.w_re.cs128[i]; csi[i] = a.w_im.cs128[i]; Dl[i] = a.D[i]; cs2[i] = a.w_o2.cs128[i];
+        if (!PK16) be[i] = a.bias_eff[i];
     }
+    if (PK16) // packed pairs (every value fits 16 bits: host-checked)
+        for (int i = threadIdx.x; i < H / 2; i += NTHR)
+            be[i] = (int32_t)(((uint32_t)a.bias_eff[2 * i] & 0xffffu) | ((uint32_t)a.bias_eff[2 * i + 1] << 16));
     if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
     if (DIRECT) {
         for (int i = threadIdx.x; i < (1 << a.sigdir_bits) / 2; i += NTHR)
@@ -149,6 +223,8 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
     const int cv_l = a.conv && a.inp_exp > a.y_exp ? a.inp_exp - a.y_exp : 0, cv_r = a.conv && a.y_exp > a.inp_exp ? a.y_exp - a.inp_exp : 0;
     const int cv_b1 = a.conv && a.inp_exp != a.y_exp ? a.y_bits : 32, cv_b2 = a.conv && a.y_bits > a.inp_bits ? a.inp_bits : 32;
     const int cv_b = cv_b1 < cv_b2 ? cv_b1 : cv_b2;
+    // PK16: change_cfg(x1 -> l operand) with equal widths is a left shift that saturates or a right shift (fxp_prims.hpp chcfg)
+    const int lq_l = a.l_exp > a.y_exp ? a.l_exp - a.y_exp : 0, lq_r = a.y_exp > a.l_exp ? a.y_exp - a.l_exp : 0;
     uint32_t xrange = 0;
     v2i16 pmax = {0, 0}, pmin = {0, 0}; // S16: running extremes of (re, im) as packed int16
     float mx[3] = {0.f, 0.f, 0.f}; // [0]: |z*kz + s| as converted integers, scaled once at the end; [1], [2] stay 0
@@ -261,6 +337,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
         __syncthreads();
         // ---- phase B1: C projection + first epilogue
         int32_t x1v[NU][16];
+        uint32_t x1p[NU][8]; // PK16: the same values as int16 pairs (channels 2q, 2q+1 of group g at [2g + q])
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int sub = sub0 + u * SUBSTEP;
@@ -272,6 +349,22 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4i Dv = *reinterpret_cast<const v4i *>(Dl + ch0 + 8 * g);
+                const int off = (32 * sub + r) * KPX + ch0 + 8 * g;
+                if constexpr (PK16) {
+                    // fxpmodel.py:746-793 + :1125 on int16 pairs: cx = sat(sat(cr) - sat(ci)); y = sat(2 cx + sat(D u)); x1 = max(y, 0)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t crp = pk_cvt(asr(are[4 * g + 2 * q], a.rs_re), asr(are[4 * g + 2 * q + 1], a.rs_re));
+                        const uint32_t cip = pk_cvt(asr(aim[4 * g + 2 * q], a.rs_im), asr(aim[4 * g + 2 * q + 1], a.rs_im));
+                        const uint32_t upk = (uint32_t)uq[u][g][q];
+                        const uint32_t dup = pk_cvt(asr(mul24_h<0>(Dv[2 * q], upk), a.rs_d), asr(mul24_h<1>(Dv[2 * q + 1], upk), a.rs_d));
+                        const uint32_t yp = pk_mad_sat(pk_sub_sat(crp, cip), 0x00020002u, dup); // 2*cx is not clipped, :765-767
+                        x1p[u][2 * g + q] = pk_max(yp, 0u);
+                    }
+                    const uint32_t p01 = x1p[u][2 * g], p23 = x1p[u][2 * g + 1];
+                    *reinterpret_cast<int32_t *>(Xl + off) = (int32_t)(perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+                    *reinterpret_cast<int32_t *>(Xh + off) = (int32_t)perm(p23, p01, 0x07050301u);
+                } else {
                 int32_t uv[4], xv[4];
                 unpack4_i16(uq[u][g], uv);
 #pragma unroll
@@ -293,9 +386,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                     for (int e = 0; e < 4; ++e) xv[e] = sat(asr(wshl(xv[e], cv_l), cv_r), cv_b);
                 }
                 const unsigned p01 = perm((unsigned)xv[1], (unsigned)xv[0], 0x05010400u), p23 = perm((unsigned)xv[3], (unsigned)xv[2], 0x05010400u);
-                const int off = (32 * sub + r) * KPX + ch0 + 8 * g;
                 *reinterpret_cast<int32_t *>(Xl + off) = (int32_t)(perm(p23, p01, 0x05040100u) ^ 0x80808080u);
                 *reinterpret_cast<int32_t *>(Xh + off) = (int32_t)perm(p23, p01, 0x07060302u);
+                }
             }
         }
         __syncthreads();
@@ -306,7 +399,32 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
             const int64_t n = n0 + 32 * sub + r;
             v16i acc;
             mfma_planes<NT>(acc, wo2, Xh + (32 * sub + r) * KPX + 16 * h, Xl + (32 * sub + r) * KPX + 16 * h, cs2 + ch0);
-            if (32 * sub + r < nvalid) {
+            if (PK16 && 32 * sub + r < nvalid) {
+                // out2 bias, table sigmoid, gate (fxpmodel.py:1133-1137, :97-144, :1075-1093) on int16 pairs
+                const uint32_t lm = 0x10001u * (uint32_t)(1 << lq_l), lr = 0x10001u * (uint32_t)lq_r;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = ch0 + 8 * g;
+                    const v2i bp = *reinterpret_cast<const v2i *>(be + (ch >> 1));
+                    v2i zo;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        uint32_t gp = pk_cvt(asr(acc[4 * g + 2 * q], a.rs_o2), asr(acc[4 * g + 2 * q + 1], a.rs_o2));
+                        gp = pk_add_sat(gp, (uint32_t)bp[q]);
+                        const int32_t r0 = sigd[ashr_h<0>(dsh, gp) + dbias], r1 = sigd[ashr_h<1>(dsh, gp) + dbias];
+                        uint32_t lp = x1p[u][2 * g + q];
+                        if (lq_l) lp = pk_mad_sat(lp, lm, 0u);      // uniform: change_cfg of the gate's l operand
+                        else if (lq_r) lp = pk_ashr(lp, lr);
+                        const uint32_t zp = pk_cvt(asr(mul24_h<0>(r0, lp), a.rs_gate), asr(mul24_h<1>(r1, lp), a.rs_gate));
+                        zo[q] = (int)zp;
+                        const uint32_t sp = (uint32_t)sq[u][g][q];
+                        mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<0>(zp), kz, cvtf_h<0>(sp))));
+                        mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<1>(zp), kz, cvtf_h<1>(sp))));
+                    }
+                    *reinterpret_cast<v2i *>(a.z + n * H + ch) = zo;
+                }
+            }
+            if (!PK16 && 32 * sub + r < nvalid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int ch = ch0 + 8 * g;

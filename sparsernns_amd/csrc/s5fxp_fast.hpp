@@ -16,6 +16,7 @@ struct FastLayer {
     const int32_t *sigtab = nullptr; // [2][7 << sig_x] (mfma_fused.hpp k_cgate_p)
     const int16_t *sigdir = nullptr; // [1 << sigdir_bits] when the sigmoid input has <= 12 bits (DIRECT)
     int sigdir_bits = 0;
+    bool bias16 = false; // every out2 bias, moved to out_exp, fits 16 bits (a condition of the gate kernel's PK16 epilogues)
 };
 
 // The recurrence keeps only B*P/16 waves busy for ~50 us per layer while the projections on either side of it
@@ -160,6 +161,11 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
         pack_mfma(p, [&](int k, int ch) { return s.C_im[(size_t)ch * P + k]; }, P, H, o.cim);
         pack_mfma(p, [&](int k, int ch) { return l.out2.weight[(size_t)k * l.out2.M + ch]; }, H, H, o.out2);
         pack_bias_eff(p, l.out2, o.out2.w.Np, o.out2);
+        o.bias16 = true;
+        for (int ch = 0; ch < l.out2.M; ++ch) {
+            const int32_t v = fxp::chexp(l.out2.bias[ch], l.out2.b_bits, l.out2.b_exp, l.out2.out_exp);
+            o.bias16 = o.bias16 && v >= -32768 && v <= 32767;
+        }
         std::vector<int32_t> Dp(o.cre.w.Np, 0);
         for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
         o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
@@ -530,6 +536,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
             const bool direct = s16 && fl.sigdir_bits > 0;
+            // packed int16 epilogues (mfma_fused.hpp PK16): every width they touch is 16, no out2 input conversion
+            static const bool no_pk16 = std::getenv("S5FXP_NO_PK16") != nullptr;
+            const bool pk16 = direct && !tr && !no_pk16 && fl.bias16 && s.y_bits == 16 && ga.out_bits == 16 && l.res_bits == 16 &&
+                              l.l_bits == 16 && !ga.conv && l.l_exp - s.y_exp <= 14;
             const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
                                 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
             if (exact) {
@@ -545,6 +555,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
+                    } else if (pk16 && pair) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, true, true>, cg, smem, a, 768);
+                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, true, true>, cg, smem, a);
+                    } else if (pk16) {
+                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, false, true>, cg, smem, a, 768);
+                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, false, true>, cg, smem, a);
                     } else if (direct && pair) {
                         if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, true>, cg, smem, a);
