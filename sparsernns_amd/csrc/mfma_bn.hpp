@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, 
 // the multi-rank hook (element-wise float MAX) can exchange them as they are.
 // ---------------------------------------------------------------------------------------------
 constexpr float EXT_BIAS = 65536.f;
+// Single-rank forwards spread the workgroups' atomics over EXT_REPS replicas of the 2H extremes (replica = blockIdx % EXT_REPS):
+// 512 workgroups hitting the same 192 words serialise at the L2 atomic units for several microseconds, and that time sits
+// on the critical path between two layers.  The finalize body folds the replicas with EXT_REPS independent loads.
+constexpr int EXT_REPS = 8;
 
 __device__ __forceinline__ void unpack8_i16(const v4i &w, int32_t (&v)[8])
 {
@@ -69,8 +73,10 @@ __device__ __forceinline__ void block_allmax(float (&v)[NV], float (*red)[8])
 // Callable by any 256-thread workgroup: as its own kernel (k_bn_finalize_mm) or as the tail of the kernel that
 // produced the extremes, run by the workgroup that finished last (k_resid_minmax16).  There the extremes were
 // written by other workgroups' atomics, possibly on other XCDs: agent-scope loads, not cached ones.
-__device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float *ext, int H, LayerDyn *d, int32_t *status,
-                                                    int32_t *status_exps, int xe)
+// Returns the derived exponents to EVERY thread; `publish` chooses the workgroup that also writes them to *d and the
+// status words (the B projection runs this in every workgroup's prologue: k_bproj_p).
+__device__ __forceinline__ LayerDyn bn_finalize_mm_body(const BnArgs &a, const float *ext, int H, LayerDyn *d, int32_t *status,
+                                                        int32_t *status_exps, int xe, int reps = 1, bool publish = true)
 {
     // This runs on the critical path between two layers (nothing else is executing), so it is written for latency:
     // every operand a channel needs is requested up front, each stage costs ONE barrier (its own reduction slots),
@@ -81,8 +87,10 @@ __device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float
     float e0 = 0.f, e1 = 0.f;
     int32_t pm = 0, pi = 0, ps = 0, pb = 0;
     if (act) {
-        e0 = __hip_atomic_load(ext + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        e1 = __hip_atomic_load(ext + H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int rp = 0; rp < reps; ++rp) {
+            e0 = fmaxf(e0, __hip_atomic_load(ext + rp * 2 * H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            e1 = fmaxf(e1, __hip_atomic_load(ext + rp * 2 * H + H + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
         pm = a.mm[h];
         pi = a.isv[h];
         if (a.scale) ps = a.scale[h];
@@ -117,10 +125,9 @@ __device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float
         if (act) {
             const float fm = tofloat(pm, a.me), f0 = tofloat(xlo, xe), f1 = tofloat(xhi, xe);
             v[0] = fmaxf(fabsf(__fadd_rn(f0, fm)), fabsf(__fadd_rn(f1, fm)));
-            v[1] = fmaxf(fabsf(f0), fabsf(f1));
-            v[2] = fabsf(fm);
         }
-        allmax(0, v, 3);
+        allmax(0, v, 1); // only max |x + y| chooses the exponent (fxparray.py:421-425); the operands' own maxima size an
+                         // intermediate width the device code does not need
         uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
         sd.mx[0] = m3[0]; sd.mx[1] = m3[1]; sd.mx[2] = m3[2];
         sd.bn1 = finalize_add_cb(m3, xe, a.me, a.b1, status);
@@ -160,16 +167,14 @@ __device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float
             const float fb = tofloat(pb, a.be);
             const float f0 = tofloat(c3(xlo), e3), f1 = tofloat(c3(xhi), e3);
             v[0] = fmaxf(fabsf(__fadd_rn(f0, fb)), fabsf(__fadd_rn(f1, fb)));
-            v[1] = fmaxf(fabsf(f0), fabsf(f1));
-            v[2] = fabsf(fb);
         }
-        allmax(3, v, 3);
+        allmax(3, v, 1);
         uint32_t m3[3] = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
         sd.mx[5] = m3[0]; sd.mx[6] = m3[1]; sd.mx[7] = m3[2];
         sd.bn4 = finalize_add_cb(m3, e3, a.be, a.b4, status);
         sd.bn_e = sd.bn4.eo;
     }
-    if (h == 0) { // publish (redo and the residual maxima slots of *d are written later in the layer)
+    if (h == 0 && publish) { // (redo and the residual maxima slots of *d are written later in the layer)
         d->bn1 = sd.bn1; d->rs2 = sd.rs2; d->e2 = sd.e2; d->rs3 = sd.rs3; d->e3 = sd.e3; d->bn4 = sd.bn4; d->bn_e = sd.bn_e;
         for (int i = 0; i < 8; ++i) d->mx[i] = sd.mx[i];
         status_exps[0] = sd.bn1.eo;
@@ -177,13 +182,14 @@ __device__ __forceinline__ void bn_finalize_mm_body(const BnArgs &a, const float
         if (a.scale) status_exps[2] = sd.e3;
         if (a.bias) status_exps[3] = sd.bn4.eo;
     }
+    return sd;
 }
 
 // stand-alone form (multi-rank mode: the extremes are exchanged between the two kernels)
 __global__ __launch_bounds__(256) void k_bn_finalize_mm(BnArgs a, const float *ext, int H, LayerDyn *d, int32_t *status,
                                                         int32_t *status_exps)
 {
-    bn_finalize_mm_body(a, ext, H, d, status, status_exps, a.xe.get());
+    (void)bn_finalize_mm_body(a, ext, H, d, status, status_exps, a.xe.get());
 }
 
 // Residual add + ReLU of one layer and, in the same pass, the per-channel extremes of its result (the next
@@ -211,12 +217,13 @@ struct ResidTail {
     int32_t *status_exps_next;
     int32_t *ticket; // zeroed with the LayerDyn block
     int32_t xe_static; // RESID=false: exponent of z
-    int32_t enable;
+    int32_t enable;    // the workgroup that finishes last derives the next layer's exponents (otherwise the consumer does)
+    int32_t reps;      // replicas of the extremes the atomics are spread over (1 or EXT_REPS)
 };
 
 constexpr int RESID_THREADS = 384;
 template <bool RESID>
-__global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
+__global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
                                                                   int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
                                                                   int64_t span, int res_bits, int skip_bits, ResidHead hd,
                                                                   float *ext, ResidTail tl, int32_t *status)
@@ -226,6 +233,24 @@ __global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t 
     __shared__ int last;
     const int G = H >> 3, R = RESID_THREADS / G;
     const int g = threadIdx.x % G, rl = threadIdx.x / G;
+    // a round = four frames per thread.  The first round's loads are issued BEFORE the head below: its exponent arithmetic
+    // needs the maxima, the loads do not.  (Double-buffering every round was tried: 171 registers, one workgroup per CU
+    // instead of three, 29 us instead of 23.)
+    const int64_t stride = R;
+    const int64_t lo_n = (int64_t)blockIdx.x * span, hi_n = lo_n + span < N ? lo_n + span : N;
+    auto fetch = [&](v4i(&zq)[4], v4i(&sq)[4], int64_t n0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t n = n0 + k * stride;
+            if (n < hi_n) {
+                zq[k] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(z + n * H + 8 * g));
+                if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
+            }
+        }
+    };
+    v4i za[4], sa[4];
+    const int64_t first = lo_n + rl, step = 4 * stride;
+    if (first < hi_n) fetch(za, sa, first);
     AddCb p{};
     if constexpr (RESID) {
         if (hd.enable) {
@@ -248,44 +273,35 @@ __global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t 
         lo[e] = 32767;
         hi[e] = -32768;
     }
-    {
-        const int64_t stride = R;
-        const int64_t lo_n = (int64_t)blockIdx.x * span, hi_n = lo_n + span < N ? lo_n + span : N;
-        for (int64_t n0 = lo_n + rl; n0 < hi_n; n0 += 4 * stride) {
-            v4i zq[4], sq[4];
+    auto process = [&](const v4i(&zq)[4], const v4i(&sq)[4], int64_t n0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t n = n0 + k * stride;
-                if (n < hi_n) {
-                    zq[k] = *reinterpret_cast<const v4i *>(z + n * H + 8 * g);
-                    if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t n = n0 + k * stride;
-                if (n < hi_n) {
-                    int32_t v[8], s[8];
-                    unpack8_i16(zq[k], v);
-                    if constexpr (RESID) {
-                        unpack8_i16(sq[k], s);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
-                            if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
-                            v[e] = rr < 0 ? 0 : rr;
-                        }
-                        const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
-                        *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
-                    }
+        for (int k = 0; k < 4; ++k) {
+            const int64_t n = n0 + k * stride;
+            if (n < hi_n) {
+                int32_t v[8], s[8];
+                unpack8_i16(zq[k], v);
+                if constexpr (RESID) {
+                    unpack8_i16(sq[k], s);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        lo[e] = v[e] < lo[e] ? v[e] : lo[e];
-                        hi[e] = v[e] > hi[e] ? v[e] : hi[e];
+                        const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
+                        if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
+                        v[e] = rr < 0 ? 0 : rr;
                     }
+                    const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
+                    *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    lo[e] = v[e] < lo[e] ? v[e] : lo[e];
+                    hi[e] = v[e] > hi[e] ? v[e] : hi[e];
                 }
             }
         }
+    };
+    for (int64_t n0 = first; n0 < hi_n; n0 += step) {
+        process(za, sa, n0);
+        if (n0 + step < hi_n) fetch(za, sa, n0 + step);
     }
     if (!ext) return;
 #pragma unroll
@@ -294,15 +310,32 @@ __global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t 
         smax[threadIdx.x * 8 + e] = hi[e];
     }
     __syncthreads();
-    if (threadIdx.x < H) { // one thread per channel folds the R frame lanes
-        const int c = threadIdx.x;
-        int32_t a = 32767, b = -32768;
-        for (int r = 0; r < R; ++r) {
-            a = min(a, smin[r * G * 8 + c]);
-            b = max(b, smax[r * G * 8 + c]);
+    {
+        // fold the R frame lanes: one thread per (bound, channel) -- two per item at H = 96, each folding half the lanes
+        const int items = 2 * H, parts = RESID_THREADS / items > 1 ? 2 : 1, per = R / parts;
+        const int item = threadIdx.x % items, part = threadIdx.x / items;
+        const bool is_max = item >= H;
+        const int c = is_max ? item - H : item;
+        int32_t v = is_max ? -32768 : 32767;
+        if (part < parts) {
+            const int32_t *src = is_max ? smax : smin;
+            for (int r = part * per; r < (part + 1) * per; ++r) {
+                const int32_t t = src[r * G * 8 + c];
+                v = is_max ? max(v, t) : min(v, t);
+            }
         }
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)a));
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + H + c, __float_as_uint(EXT_BIAS + (float)b));
+        __syncthreads();
+        if (parts == 2 && part == 1) smin[item] = v; // the arrays are free now
+        __syncthreads();
+        if (part == 0) {
+            if (parts == 2) {
+                const int32_t t = smin[item];
+                v = is_max ? max(v, t) : min(v, t);
+            }
+            const int rep = tl.reps > 1 ? (int)(blockIdx.x % tl.reps) : 0;
+            atomicMax(reinterpret_cast<uint32_t *>(ext) + rep * 2 * H + item,
+                      __float_as_uint(is_max ? EXT_BIAS + (float)v : EXT_BIAS - (float)v));
+        }
     }
     if (!tl.enable) return;
     // the extremes are agent-scope atomics; once this workgroup's are acknowledged it takes a ticket
@@ -310,7 +343,7 @@ __global__ __launch_bounds__(RESID_THREADS) void k_resid_minmax16(const int16_t 
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
     __syncthreads();
-    if (last) bn_finalize_mm_body(tl.bn, ext, H, tl.d_next, status, tl.status_exps_next, RESID ? p.eo : tl.xe_static);
+    if (last) (void)bn_finalize_mm_body(tl.bn, ext, H, tl.d_next, status, tl.status_exps_next, RESID ? p.eo : tl.xe_static, tl.reps);
 }
 
 
@@ -390,6 +423,11 @@ struct BprojM2Args {
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
     int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
     int32_t k_re;        // SM = 2 (pair-native K stream): 2^16 - 2^(16 - A_re_exp), the addend of the negated product
+    // != nullptr: the per-channel extremes of the layer input (ext_reps replicas of 2H floats); every workgroup derives the
+    // BatchNorm exponents from them in its prologue (bn_finalize_mm_body), workgroup 0 publishes them
+    const float *ext;
+    int32_t ext_reps;
+    int32_t *status, *status_exps;
 };
 
 } // namespace s5

@@ -93,7 +93,13 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
         for (int ks = 0; ks < KS; ++ks)
             wreg[c][ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)col * a.w.Kp + 32 * ks + 16 * h);
     }
-    const LayerDyn d = *a.bn.dyn;
+    // The BatchNorm exponents of this layer: read from *dyn, or -- single-rank forwards -- derived here, by every
+    // workgroup for itself, from the per-channel extremes the producer of the layer input left behind (the first tile's
+    // loads are in flight meanwhile).  A single workgroup doing this at the tail of the producer kernel cost 4-7 us of
+    // serialised round trips (atomics -> ticket -> loads -> arithmetic) on the critical path between two layers.
+    const LayerDyn d = a.ext ? bn_finalize_mm_body(a.bn, a.ext, H, const_cast<LayerDyn *>(a.bn.dyn), a.status, a.status_exps, a.bn.xe.get(), a.ext_reps,
+                                                   blockIdx.x == 0)
+                             : *a.bn.dyn;
     const Bn16 bn = bn16_setup(a.bn, d, tab, H);
     __syncthreads();
 
@@ -410,8 +416,9 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
     __syncthreads();
     if (threadIdx.x < a.M) { // max = ehi, min = 65535 - elo; as the positive floats of mfma_bn.hpp
         const int c = threadIdx.x;
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + c, __float_as_uint(EXT_BIAS - (float)(65535 - (int)elo[c])));
-        atomicMax(reinterpret_cast<uint32_t *>(ext) + a.M + c, __float_as_uint(EXT_BIAS + (float)ehi[c]));
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ext) + (tl.reps > 1 ? (int)(blockIdx.x % tl.reps) : 0) * 2 * a.M;
+        atomicMax(dst + c, __float_as_uint(EXT_BIAS - (float)(65535 - (int)elo[c])));
+        atomicMax(dst + a.M + c, __float_as_uint(EXT_BIAS + (float)ehi[c]));
     }
     if (!tl.enable) return;
     __shared__ int last;
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
     __syncthreads();
-    if (last) bn_finalize_mm_body(tl.bn, ext, a.M, tl.d_next, a.status, tl.status_exps_next, tl.xe_static);
+    if (last) (void)bn_finalize_mm_body(tl.bn, ext, a.M, tl.d_next, a.status, tl.status_exps_next, tl.xe_static, tl.reps);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -224,7 +224,7 @@ FastWs fast_ws(const s5fxp_model *m, int B, int L)
     w.xs = off; off += ns;
     // per-layer device state and per-channel extremes: contiguous, zeroed by one memset per forward
     w.dyn = off; off += al(sizeof(LayerDyn) * (size_t)m->n_layers);
-    w.ext = off; off += al(sizeof(float) * 2 * (size_t)m->H * (size_t)m->n_layers);
+    w.ext = off; off += al(sizeof(float) * 2 * (size_t)m->H * (size_t)m->n_layers * EXT_REPS);
     w.dyn_bytes = off - w.dyn;
     w.total = off;
     return w;
@@ -335,11 +335,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // lets the last workgroup derive layer 0's BatchNorm exponents (mfma_bn.hpp ResidTail)
         float *ext0 = bn_ext && m->n_layers > 0 ? reinterpret_cast<float *>(ws + w.ext) : nullptr;
         ResidTail tl{};
-        if (ext0 && bn_ext && !allreduce) {
-            tl.bn = make_bn(0, m->enc.out_bits, DynExp{m->enc.out_exp, nullptr});
-            tl.d_next = dyn; tl.status_exps_next = status + 8; tl.ticket = &dyn->pad1[0];
-            tl.xe_static = m->enc.out_exp; tl.enable = 1;
-        }
+        tl.reps = (ext0 && !allreduce) ? EXT_REPS : 1; // the consumer (k_bproj_p's prologue) derives the exponents: tl.enable = 0
         if (big) launch6x(k_enc_p<6>, smem, a, ext0, tl);
         else launch6x(k_enc_p<3>, smem, a, ext0, tl);
     }
@@ -374,7 +370,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             return allreduce ? allreduce(allreduce_ctx, reinterpret_cast<float *>(d->mx + slot), n, (void *)st) : 0;
         };
         if (bn_ext) {
-            float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H;
+            float *ext = reinterpret_cast<float *>(ws + w.ext) + (size_t)li * 2 * H * EXT_REPS;
             // layer 0: extremes of the encoder output; later layers: the previous layer's residual pass left them
             // layer 0: the encoder left the extremes; later layers: the previous layer's residual pass
             if (!fold) {
@@ -425,6 +421,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
             a.k_re = 65536 - (1 << (16 - s.A_re_exp));
+            if (fold) {
+                a.ext = reinterpret_cast<const float *>(ws + w.ext) + (size_t)li * 2 * H * EXT_REPS;
+                a.ext_reps = EXT_REPS; a.status = status; a.status_exps = st_exps;
+            }
             // phase-split kernel (proj_p.hpp): 64-step tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
             for (int k = 0; k < n_chunks; ++k) {
@@ -622,15 +622,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps, redo_slot);
         if (bn_ext) {
             const bool more = li + 1 < m->n_layers;
-            float *ext_next = more ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H : nullptr;
+            float *ext_next = more ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H * EXT_REPS : nullptr;
             ResidHead hd{};
             hd.d = d; hd.res_exp = l.res_exp; hd.skip_e = he; hd.redo_slot = redo_slot; hd.status_exps = st_exps;
             hd.enable = fold ? 1 : 0;
             ResidTail tl{};
-            if (more && fold) {
-                tl.bn = make_bn(li + 1, l.res_bits, DynExp{0, &d->res.eo});
-                tl.d_next = d + 1; tl.status_exps_next = st_exps + 8; tl.ticket = &(d + 1)->pad1[0]; tl.enable = 1;
-            }
+            tl.reps = (more && fold) ? EXT_REPS : 1; // the next layer's B projection derives its exponents from the extremes
             hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(rm_grid), dim3(RESID_THREADS), 0, st, (const int16_t *)I16(w.z),
                                (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, rm_span, l.res_bits, hb, hd, ext_next, tl,
                                status);
