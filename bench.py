@@ -34,16 +34,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def pmc_traffic(B, L, P, kernel):
-    """HBM bytes per recurrence launch from the committed PMC passes (profiles/r01_scan_traffic.json: FETCH_SIZE
+    """HBM bytes per recurrence launch from the committed PMC passes (profiles/r0N_scan_traffic.json: FETCH_SIZE
     doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), if they were taken on this workload."""
-    p = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
-    if not os.path.exists(p):
-        return None
-    with open(p) as f:
-        t = json.load(f)
-    if (t["B"], t["L"], t["P"]) != (B, L, P) or kernel not in t["kernels"]:
-        return None
-    return t["kernels"][kernel]["traffic_bytes_per_launch"]
+    for name in ("r02_scan_traffic.json", "r01_scan_traffic.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(p):
+            continue
+        with open(p) as f:
+            t = json.load(f)
+        if (t["B"], t["L"], t["P"]) == (B, L, P) and kernel in t["kernels"]:
+            return t["kernels"][kernel]["traffic_bytes_per_launch"]
+    return None
 
 
 def launch_ranks(n: int) -> int:
