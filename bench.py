@@ -236,9 +236,12 @@ def main() -> None:
 
     run.runner = None
 
+    def lanes_of(d):  # engine lanes the d batches in flight use: 0 for the one-at-a-time pass, the runner's own otherwise
+        return [0] if d == 1 else [run.runner.lane_of(i) for i in range(d)]
+
     def check_all(d):
         bits = 0
-        for lane in range(d):
+        for lane in lanes_of(d):
             bits |= int(eng.check_status(lane)[0])
         if bits & _lib.ST_REDO:
             raise SystemExit("a state left the fast recurrence's exact range: the timed steps are invalid; "
@@ -259,7 +262,7 @@ def main() -> None:
     run(probe, depth)
     torch.cuda.synchronize()
     bits = 0
-    for lane in range(depth):
+    for lane in lanes_of(depth):
         bits |= int(eng.check_status(lane)[0])
     if bits & _lib.ST_REDO:
         fallback_note = "states left the 16-bit fast range: exact kernels (S5FXP_FWD_EXACT) for every step"

@@ -7,6 +7,7 @@
 #include "mfma_fused.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>

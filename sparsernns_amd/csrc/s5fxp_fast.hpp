@@ -19,43 +19,9 @@ struct FastLayer {
     bool bias16 = false; // every out2 bias, moved to out_exp, fits 16 bits (a condition of the gate kernel's PK16 epilogues)
 };
 
-// The recurrence keeps only B*P/16 waves busy for ~50 us per layer while the projections on either side of it
-// want the whole chip: each layer's bproj | scan | cgate sequence is cut into step chunks, the scan chunks run
-// on a side stream (created with the model, highest priority) and overlap the projections of their neighbours.
-constexpr int MAX_CHUNKS = 8;
-struct Pipeline {
-    hipStream_t side = nullptr;
-    hipEvent_t ev_b[MAX_CHUNKS] = {}, ev_s[MAX_CHUNKS] = {};
-    bool ok = false, tried = false;
-    int chunks = 1; // measured (profiles/r01_pipeline_chunks.txt): cross-queue waits cost 12-22 us per hop, 2 chunks are 10 % slower
-    void init()
-    {
-        tried = true;
-        if (const char *e = std::getenv("S5FXP_CHUNKS")) chunks = std::atoi(e);
-        if (chunks < 2 || chunks > MAX_CHUNKS) return; // 1 (default): no pipelining; S5FXP_CHUNKS=2..8 to experiment
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest) != hipSuccess) { side = nullptr; return; }
-        for (int i = 0; i < MAX_CHUNKS; ++i)
-            if (hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_s[i], hipEventDisableTiming) != hipSuccess)
-                return;
-        ok = true;
-    }
-    ~Pipeline()
-    {
-        for (int i = 0; i < MAX_CHUNKS; ++i) {
-            if (ev_b[i]) (void)hipEventDestroy(ev_b[i]);
-            if (ev_s[i]) (void)hipEventDestroy(ev_s[i]);
-        }
-        if (side) (void)hipStreamDestroy(side);
-    }
-};
-
 struct FastModel {
     MfmaWDev enc, dec;
     std::vector<FastLayer> layers;
-    mutable Pipeline pipe; // one forward at a time per model handle
 };
 
 namespace {
@@ -257,6 +223,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const bool exact = opts && (opts->flags & S5FXP_FWD_EXACT);
     const bool defer = opts && (opts->flags & S5FXP_FWD_DEFER_REDO) && !exact;
     const FastWs w = fast_ws(m, B, L);
+    // S5FXP_DEBUG_SYNC=1: synchronise and check for launch / execution errors after every stage (names the stage that failed);
+    // off by default -- a forward has no host synchronisation, and launch errors are collected once at the end
+    static const bool debug_sync = std::getenv("S5FXP_DEBUG_SYNC") != nullptr;
+    auto stage_ok = [&](const char *what, int layer) -> bool {
+        if (!debug_sync) return true;
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) std::fprintf(stderr, "[s5fxp] %s (layer %d): %s\n", what, layer, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
     char *ws = reinterpret_cast<char *>(workspace);
     auto I16 = [&](size_t off) { return reinterpret_cast<int16_t *>(ws + off); };
     auto I32 = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
@@ -338,17 +315,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         tl.reps = (ext0 && !allreduce) ? EXT_REPS : 1; // the consumer (k_bproj_p's prologue) derives the exponents: tl.enable = 0
         if (big) launch6x(k_enc_p<6>, smem, a, ext0, tl);
         else launch6x(k_enc_p<3>, smem, a, ext0, tl);
-    }
-    // step chunks of the bproj | scan | cgate pipeline (see Pipeline): multiples of 64 steps, the last takes the rest
-    int n_chunks = 1, c_lo[MAX_CHUNKS + 1] = {0, L};
-    if (!exact && !traces && !allreduce) {
-        if (!F.pipe.tried) F.pipe.init();
-        const int base = (L / (F.pipe.chunks > 0 ? F.pipe.chunks : 1)) / 64 * 64;
-        if (F.pipe.ok && base >= 256) {
-            n_chunks = F.pipe.chunks;
-            for (int k = 0; k < n_chunks; ++k) c_lo[k] = k * base;
-            c_lo[n_chunks] = L;
-        }
+        if (!stage_ok("encoder", -1)) return S5FXP_EHIP;
     }
     // single-rank mode folds the two one-workgroup "finalize" kernels of every layer into the residual pass
     // (mfma_bn.hpp k_resid_minmax16); with a multi-rank hook the maxima are exchanged in between, so they stay
@@ -403,7 +370,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // optimistic forwards (the caller repeats with S5FXP_FWD_EXACT if the range check fires) keep both recurrence
         // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
         // B projection's output, of both sides of the recurrence and of the gate kernel's state input
-        const bool s16 = defer && quad && !tr && n_chunks == 1 && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
+        const bool s16 = defer && quad && !tr && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
         // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
         // per state, four instructions per step; K stream int32 in, int16 states out).  S5FXP_NO_PAIR=1 (tests, profiling)
         static const bool no_pair = std::getenv("S5FXP_NO_PAIR") != nullptr;
@@ -427,8 +394,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             }
             // phase-split kernel (proj_p.hpp): 64-step tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
-            for (int k = 0; k < n_chunks; ++k) {
-                a.t_lo = c_lo[k]; a.t_len = c_lo[k + 1] - c_lo[k];
+            {
+                a.t_lo = 0; a.t_len = L;
                 const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? 512 : 1024, per = (tl + cap - 1) / cap;
                 const unsigned bthr = big ? 512 : 256; // one wave per 32-column tile of [B_re | B_im]
                 const unsigned pgrid = (unsigned)((tl + per - 1) / per);
@@ -450,16 +417,14 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr);
                     else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr);
                 }
-                if (n_chunks > 1 && (rc = hip_rc(hipEventRecord(F.pipe.ev_b[k], st)))) return rc;
             }
         }
+        if (!stage_ok("B projection", li)) return S5FXP_EHIP;
         // ---- recurrence
         const size_t plane = (size_t)B * P;
         const int32_t *x0_re = state_in ? state_in + (size_t)li * 2 * plane : nullptr, *x0_im = state_in ? x0_re + plane : nullptr;
         int32_t xmax = 32767; // the C projection's 16-bit planes
-        const bool piped = quad && n_chunks > 1;
-        hipStream_t sst = piped ? F.pipe.side : st; // the stream the recurrence runs on
-        if (piped && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[0], 0)))) return rc;
+        hipStream_t sst = st; // the stream the recurrence runs on
         if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], sst)))) return rc;
         if (pairl) {
             ScanPairLArgs q{};
@@ -481,15 +446,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
-            for (int k = 0; k < (piped ? n_chunks : 1); ++k) {
-                if (piped) {
-                    if (k > 0 && (rc = hip_rc(hipStreamWaitEvent(sst, F.pipe.ev_b[k], 0)))) return rc;
-                    q.tb0 = c_lo[k] / 4;
-                    q.ntb = k + 1 < n_chunks ? (c_lo[k + 1] - c_lo[k]) / 4 : 0; // the last chunk runs to the padded end
-                }
+            {
                 if (s16) hipLaunchKernelGGL(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
                 else hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
-                if (piped && (rc = hip_rc(hipEventRecord(F.pipe.ev_s[k], sst)))) return rc;
             }
             xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
             if (s16 && xmax > 32766) xmax = 32766; // a saturated int16 state must fail the check
@@ -501,6 +460,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
         }
         if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], sst)))) return rc;
+        if (!stage_ok("recurrence", li)) return S5FXP_EHIP;
         // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
         GateMArgs ga{};
         bool fused = false;
@@ -546,10 +506,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
             } else {
-                const int nck = piped ? n_chunks : 1;
-                for (int k = 0; k < nck; ++k) {
-                    a.t_lo = piped ? c_lo[k] : 0; a.t_len = piped ? c_lo[k + 1] - c_lo[k] : L;
-                    if (piped && (rc = hip_rc(hipStreamWaitEvent(st, F.pipe.ev_s[k], 0)))) return rc;
+                {
+                    a.t_lo = 0; a.t_len = L;
                     const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + 511) / 512;
                     const unsigned cg = (unsigned)((tl + per - 1) / per);
                     if (tr) {
@@ -612,6 +570,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);
         }
+        if (!stage_ok("gate kernel", li)) return S5FXP_EHIP;
         if (allreduce) {
             // ranks may differ in `redo`: move the valid maxima to slots 8..10 before they are exchanged
             if (fused) hipLaunchKernelGGL(k_select_maxima, dim3(1), dim3(64), 0, st, d);
@@ -635,6 +594,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z),
                                (const int16_t *)h, hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);
         }
+        if (!stage_ok("residual pass", li)) return S5FXP_EHIP;
         int16_t *sw = h; h = hn; hn = sw;
         hb = l.res_bits;
         he = DynExp{0, &d->res.eo};
@@ -649,6 +609,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const size_t smem = 2 * 64 * (size_t)(H + 16);
         if (big) launch6(k_dec_p<6>, smem, a);
         else launch6(k_dec_p<3>, smem, a);
+        if (!stage_ok("decoder", -1)) return S5FXP_EHIP;
     }
     return launch_rc();
 }

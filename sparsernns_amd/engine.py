@@ -304,6 +304,9 @@ class InflightRunner:
         self.streams = [torch.cuda.Stream(device=engine.device) for _ in range(depth)]
         self._pending: List[Optional[tuple]] = [None] * depth
         self._next = 0
+        # engine lanes 1..depth: lane 0 (its workspace and status words) stays Engine.forward's, which may run on
+        # another stream while batches are in flight here
+        self._lane0 = 1
 
     def submit(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int, check: bool = True,
                scan_events: Optional[list] = None) -> int:
@@ -317,7 +320,12 @@ class InflightRunner:
         s.wait_stream(torch.cuda.current_stream(self.engine.device))
         flags = _lib.FWD_EXACT if self.engine.redo_seen >= 2 else _lib.FWD_DEFER_REDO
         with torch.cuda.stream(s):
-            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=flags, lane=lane, scan_events=scan_events)
+            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=flags, lane=self._lane0 + lane, scan_events=scan_events)
+        # the tensors were allocated on another stream: tell the caching allocator that this lane's stream uses them, so
+        # that dropping the previous job's references below (check=False) cannot hand their memory out while kernels of
+        # this stream still read or write it
+        x.record_stream(s)
+        y.record_stream(s)
         self._pending[lane] = (x, x_bits, x_exp, y, B, L)
         return lane
 
@@ -328,14 +336,18 @@ class InflightRunner:
         self._pending[lane] = None
         s = self.streams[lane]
         s.synchronize()
-        st = self.engine.check_status(lane)
+        st = self.engine.check_status(self._lane0 + lane)
         if st[0] & _lib.ST_REDO:
             self.engine.redo_seen += 1
             x, x_bits, x_exp, y, B, L = job
             with torch.cuda.stream(s):
-                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_EXACT, lane=lane)
+                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_EXACT, lane=self._lane0 + lane)
             s.synchronize()
-            self.engine.check_status(lane)
+            self.engine.check_status(self._lane0 + lane)
+
+    def lane_of(self, slot: int) -> int:
+        """Engine lane (status words, workspace) of in-flight slot `slot`."""
+        return self._lane0 + slot
 
     def drain(self) -> None:
         for lane in range(self.depth):

@@ -512,3 +512,38 @@ def test_fxputils_separate_exponents_and_batchnorm_scale_quirk():
         fxputils.create_fxp_qconfig(md2, agg="mean")
     full, joined = fxputils.create_fxp_qconfig(fxputils.load_modeldict(*synth.reference_trees(md, stats, dims["n_layers"])), agg="set")
     assert isinstance(joined["blocks"]["ssm"]["activations"]["u"]["fracbits"], list) and "layers_0" in full["blocks"]["ssm"]
+
+
+def test_pickle_converter_reads_array_trees_only(tmp_path):
+    """tools/reference_pickles_to_npz.py (the run-elsewhere step in front of fxputils): pickles written HERE by this test --
+    NumPy trees shaped like the reference's calibration output -- convert to the npz pair fxputils reads, and a pickle that
+    references anything but arrays and containers is refused before it can run."""
+    import importlib.util
+    import pickle
+
+    from sparsernns_amd import fxputils
+
+    spec = importlib.util.spec_from_file_location("conv", os.path.join(ROOT, "tools", "reference_pickles_to_npz.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    md, stats, dims = _calibrated()
+    params, st = synth.reference_trees(md, stats, dims["n_layers"])
+    folder = tmp_path / "data"
+    folder.mkdir()
+    for name, tree in (("sc_calibrated_params.pkl", params), ("sc_cal_stats.pkl", st)):
+        with open(folder / name, "wb") as f:
+            pickle.dump(tree, f)
+    assert conv.main(["calib", str(folder), str(tmp_path / "m")]) == 0
+    _, qc = fxputils.derive(fxputils.load_tree_npz(tmp_path / "m.params.npz"), fxputils.load_tree_npz(tmp_path / "m.stats.npz"), "w8a16")
+    assert _same_numbers(synth.derive_qconfig(md, stats, dims["n_layers"]), qc) > 150
+    evil = pickle.dumps({"x": os.getcwd})  # a global that is not an array constructor
+    with pytest.raises(pickle.UnpicklingError):
+        conv.load_arrays_only(evil)
+    # the exported-integer-model form
+    m = O.RegressionModel(md, synth.derive_qconfig(md, stats, dims["n_layers"]), dims["n_layers"])
+    with open(folder / "fxpmodel.pkl", "wb") as f:
+        pickle.dump(m.export(), f)
+    assert conv.main(["export", str(folder), str(tmp_path / "e")]) == 0
+    from sparsernns_amd import fxprun
+    ex, meta = fxprun.load_export(str(tmp_path / "e.npz"), str(tmp_path / "e.json"))
+    tree_equal(ex["params"], m.export()["params"], "params")

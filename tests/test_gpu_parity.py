@@ -385,26 +385,6 @@ def test_fxprun_cli_validate_verify_export_reload(tmp_path):
     assert np.array_equal(np.load(o1), np.load(o2))
 
 
-def test_step_chunk_pipeline_knob_is_exact():
-    """S5FXP_CHUNKS=2: bproj | scan | cgate in two step chunks with the recurrence on a side stream (the scan
-    kernel starts its second chunk from the stored last state of the first).  Off by default (slower), but the
-    step-range arguments and the initial-state input must stay right."""
-    import os
-    from sparsernns_amd.fxparray import FxpArray
-    from sparsernns_amd.fxpmodel import build_regression_model
-
-    md, qc, dims = _make(dict(dim_scale=0.5))
-    fx = _input(qc, dims, 2, 576, seed=21)  # chunks [0,256) and [256,576): the second one is ragged
-    os.environ["S5FXP_CHUNKS"] = "2"
-    try:
-        model = build_regression_model(md, qc, dims["n_layers"])
-        y = model.engine().forward(FxpArray(fx.data, fx.bits, fx.exp))
-    finally:
-        del os.environ["S5FXP_CHUNKS"]
-    ref, _, _, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
-    assert np.array_equal(y.numpy(), ref)
-
-
 def test_denoise_pipeline_on_device_uses_the_exact_model():
     """fxprun.py:63-78 on the device: STFT -> fixed-point model -> mask -> iSTFT.  The model's part must be the
     oracle's output for the integer input the pipeline built; the rest is float tensor code checked against scipy in
