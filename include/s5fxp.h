@@ -206,8 +206,11 @@ enum {
  *               the forward with S5FXP_FWD_EXACT.  The recurrence streams are then kept as int16 where the model's
  *               Bu configuration guarantees they fit (half the bytes; a state beyond 16 bits saturates and raises
  *               S5FXP_ST_REDO like any other state outside the fast kernels' range);
- *   EXACT       skip the fast recurrence, run the exact kernels only. */
-enum { S5FXP_FWD_DEFER_REDO = 1, S5FXP_FWD_EXACT = 2 };
+ *   EXACT       skip the fast recurrence, run the exact kernels only;
+ *   NO_PAIR     (with DEFER_REDO) use the quad kernel with int16 streams instead of the pair kernel: its bound on
+ *               |state| is the full 16 bits, the pair kernel's is tighter by what the folded Bu needs -- the middle rung
+ *               of a caller's pair -> quad -> exact ladder. */
+enum { S5FXP_FWD_DEFER_REDO = 1, S5FXP_FWD_EXACT = 2, S5FXP_FWD_NO_PAIR = 4 };
 
 /* Cross-rank hook for the data-dependent exponents (mode A): when not NULL it is
  * called once per compute_best op, after the local float32 maxima (n <= 4 floats, device memory)
@@ -253,6 +256,11 @@ int s5fxp_model_is_fast(const s5fxp_model *m);
  * 4 the same pair kernel fed through LDS by a helper wave from an int16 Bu stream (the default where it applies).
  * -1: bad argument.  The exact re-run (S5FXP_FWD_EXACT) always uses the 32-bit quad kernel on the MFMA path. */
 int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer);
+/* The bound on |state| up to which that kernel is exact (the consumer of the states checks it on the data and raises
+ * S5FXP_ST_REDO / runs the exact kernels beyond it): 32766 at most for the int16-stream kernels, less for the pair
+ * kernel when the layer's coefficients and Bu width leave less room.  0: no bound (generic 32-bit recurrence), -1: bad
+ * argument. */
+int s5fxp_model_recurrence_xmax(const s5fxp_model *m, int layer);
 
 #ifdef __cplusplus
 }

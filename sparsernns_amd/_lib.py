@@ -23,7 +23,7 @@ VOIDP = C.c_void_p
 
 S5FXP_OK, S5FXP_EBADARG, S5FXP_ENEGSHIFT, S5FXP_EUNSUPPORTED, S5FXP_EHIP, S5FXP_EWORKSPACE = 0, -1, -2, -3, -4, -5
 ST_NEGSHIFT, ST_NEGEXP, ST_WIDE_STATE, ST_WIDE_INPUT, ST_REDO = 1, 2, 4, 8, 16
-FWD_DEFER_REDO, FWD_EXACT = 1, 2
+FWD_DEFER_REDO, FWD_EXACT, FWD_NO_PAIR = 1, 2, 4
 STATUS_WORDS = 128
 MODEL_DEFAULT, MODEL_FORCE_DENSE, MODEL_FORCE_CSR, MODEL_FORCE_GENERIC = 0, 1, 2, 4
 
@@ -111,6 +111,7 @@ def _load():
         "s5fxp_model_out_bits": (i, [p]),
         "s5fxp_model_is_fast": (i, [p]),
         "s5fxp_model_recurrence_kernel": (i, [p, i]),
+        "s5fxp_model_recurrence_xmax": (i, [p, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale: rebuild
@@ -122,7 +123,7 @@ lib = _load()
 EXPORTED_SYMBOLS = ("s5fxp_version s5fxp_strerror s5fxp_from_fp s5fxp_to_float s5fxp_change_cfg s5fxp_dense s5fxp_dense_csr s5fxp_add "
                     "s5fxp_mul s5fxp_add_cb s5fxp_mul_cb s5fxp_relu s5fxp_sigmoid s5fxp_scan s5fxp_model_blob_bytes "
                     "s5fxp_model_create s5fxp_model_destroy s5fxp_workspace_bytes s5fxp_model_forward "
-                    "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast s5fxp_model_recurrence_kernel").split()
+                    "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast s5fxp_model_recurrence_kernel s5fxp_model_recurrence_xmax").split()
 
 
 def check(rc: int, what: str = "") -> None:

@@ -504,6 +504,16 @@ extern "C" int s5fxp_model_out_exp(const s5fxp_model *m) { return m ? m->dec.out
 extern "C" int s5fxp_model_out_bits(const s5fxp_model *m) { return m ? m->dec.out_bits : 0; }
 /* 1 if the int8-MFMA path was packed for this model (it also needs L % 4 == 0 at run time) */
 extern "C" int s5fxp_model_is_fast(const s5fxp_model *m) { return m && m->fast ? 1 : 0; }
+extern "C" int s5fxp_model_recurrence_xmax(const s5fxp_model *m, int layer)
+{
+    const int k = s5fxp_model_recurrence_kernel(m, layer);
+    if (k < 0) return -1;
+    const LayerDev &l = m->layers[layer];
+    if (k >= 3) return l.pair_xmax;
+    if (k == 2) return l.quad_xmax < 32766 ? l.quad_xmax : 32766;
+    return l.quad_ok ? l.quad_xmax : 0;
+}
+
 extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
 {
     if (!m || layer < 0 || layer >= m->n_layers) return -1;

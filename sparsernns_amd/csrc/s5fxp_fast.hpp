@@ -374,7 +374,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
         // per state, four instructions per step; K stream int32 in, int16 states out).  S5FXP_NO_PAIR=1 (tests, profiling)
         static const bool no_pair = std::getenv("S5FXP_NO_PAIR") != nullptr;
-        const bool pair = s16 && l.pair_ok && !no_pair;
+        const bool pair = s16 && l.pair_ok && !no_pair && !(opts && (opts->flags & S5FXP_FWD_NO_PAIR));
         // the pair kernel is fed either from an int16 Bu stream through LDS by a helper wave (default: the HBM bytes of the
         // quad16 path) or from an int32 K stream in global memory (S5FXP_PAIR_GLOBAL=1)
         static const bool pair_global = std::getenv("S5FXP_PAIR_GLOBAL") != nullptr;

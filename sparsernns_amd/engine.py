@@ -55,9 +55,11 @@ class Engine:
         # a lane = the per-forward mutable state (status words + workspace); forwards on different lanes may be
         # in flight at the same time on different streams (InflightRunner).  Lane 0 is the default.
         self._status = {0: torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)}
-        # optimistic forwards that came back with ST_REDO; after two, forward() / InflightRunner stop trying the fast
-        # recurrence for this model (its states do not fit) and enqueue the exact kernels directly
-        self.redo_seen = 0
+        # The ladder of recurrence kernels an optimistic forward climbs when ST_REDO comes back: 0 pair kernel (tightest bound
+        # on |state|), 1 quad kernel with int16 streams (16 bits), 2 exact 32-bit kernels.  `level` is where forwards start;
+        # a rung that failed twice is not tried again for this model.
+        self.level = 0
+        self._redos = [0, 0]
         self._wsl: Dict[int, tuple] = {}
         self._cb_keep = None
 
@@ -118,6 +120,35 @@ class Engine:
             L.lut[j] = int(lut[j])
 
     # -- forward ---------------------------------------------------------------------------------
+    LEVEL_FLAGS = (_lib.FWD_DEFER_REDO, _lib.FWD_DEFER_REDO | _lib.FWD_NO_PAIR, _lib.FWD_EXACT)
+
+    @property
+    def redo_seen(self) -> int:  # kept for callers of the two-rung form: 2 = "go straight to the exact kernels"
+        return 2 if self.level >= 2 else 0
+
+    @redo_seen.setter
+    def redo_seen(self, v: int) -> None:
+        if v >= 2:
+            self.level = 2
+
+    def note_redo(self, level: int) -> int:
+        """An optimistic forward at `level` came back with ST_REDO: returns the rung to repeat it on."""
+        if level < 2:
+            self._redos[level] += 1
+            if self._redos[level] >= 2 and self.level <= level:
+                self.level = level + 1
+        return min(level + 1, 2)
+
+    def run_ladder(self, launch: Callable[[int], None], check: Callable[[], np.ndarray]) -> None:
+        """launch(flags) enqueues the forward, check() returns the status words (after synchronising)."""
+        level = self.level
+        while True:
+            launch(self.LEVEL_FLAGS[level])
+            st = check()
+            if not (st[0] & _lib.ST_REDO) or level >= 2:
+                return
+            level = self.note_redo(level)
+
     @property
     def status(self) -> torch.Tensor:
         return self._status[0]
@@ -223,13 +254,11 @@ class Engine:
         else:
             # the status words are read anyway: run optimistically and repeat with the exact kernels if a state
             # left the fast recurrence's range (never with a multi-rank hook: ranks must enqueue the same work)
-            first = 0 if allreduce else (_lib.FWD_EXACT if self.redo_seen >= 2 else _lib.FWD_DEFER_REDO)
-            self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=first)
-            st = self.check_status()
-            if st[0] & _lib.ST_REDO:
-                self.redo_seen += 1
-                self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=_lib.FWD_EXACT)
+            if allreduce:  # self-contained: the gated exact kernels are part of the one enqueue
+                self.enqueue(data, x.bits, x.exp, y, B, L, tr, allreduce, flags=0)
                 self.check_status()
+            else:
+                self.run_ladder(lambda fl: self.enqueue(data, x.bits, x.exp, y, B, L, tr, None, flags=fl), self.check_status)
         out = FxpArray(y, self.out_bits, self.out_exp, True)
         return (out, tr) if traces else out
 
@@ -252,13 +281,9 @@ class Engine:
             raise ValueError("empty chunk")
         y = torch.empty(tuple(data.shape[:-1]) + (self.d_out,), dtype=torch.int32, device=data.device)
         new_state = torch.empty((self.n_layers, 2, B, self.P), dtype=torch.int32, device=data.device)
-        first = _lib.FWD_EXACT if self.redo_seen >= 2 else _lib.FWD_DEFER_REDO
-        self.enqueue(data, x.bits, x.exp, y, B, L, flags=first, state_in=state, state_out=new_state)
-        st = self.check_status()
-        if st[0] & _lib.ST_REDO:  # `state` is untouched: repeat the chunk with the exact kernels
-            self.redo_seen += 1
-            self.enqueue(data, x.bits, x.exp, y, B, L, flags=_lib.FWD_EXACT, state_in=state, state_out=new_state)
-            self.check_status()
+        # `state` is never written: a chunk that comes back with ST_REDO is repeated from it on the next rung
+        self.run_ladder(lambda fl: self.enqueue(data, x.bits, x.exp, y, B, L, flags=fl, state_in=state, state_out=new_state),
+                        self.check_status)
         return FxpArray(y, self.out_bits, self.out_exp, True), new_state
 
     def stream(self, B: int = 1) -> "StreamingSession":
@@ -318,15 +343,16 @@ class InflightRunner:
             self._finish(lane)
         s = self.streams[lane]
         s.wait_stream(torch.cuda.current_stream(self.engine.device))
-        flags = _lib.FWD_EXACT if self.engine.redo_seen >= 2 else _lib.FWD_DEFER_REDO
+        level = self.engine.level
         with torch.cuda.stream(s):
-            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=flags, lane=self._lane0 + lane, scan_events=scan_events)
+            self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=Engine.LEVEL_FLAGS[level], lane=self._lane0 + lane,
+                                scan_events=scan_events)
         # the tensors were allocated on another stream: tell the caching allocator that this lane's stream uses them, so
         # that dropping the previous job's references below (check=False) cannot hand their memory out while kernels of
         # this stream still read or write it
         x.record_stream(s)
         y.record_stream(s)
-        self._pending[lane] = (x, x_bits, x_exp, y, B, L)
+        self._pending[lane] = (x, x_bits, x_exp, y, B, L, level)
         return lane
 
     def _finish(self, lane: int) -> None:
@@ -336,14 +362,14 @@ class InflightRunner:
         self._pending[lane] = None
         s = self.streams[lane]
         s.synchronize()
+        x, x_bits, x_exp, y, B, L, level = job
         st = self.engine.check_status(self._lane0 + lane)
-        if st[0] & _lib.ST_REDO:
-            self.engine.redo_seen += 1
-            x, x_bits, x_exp, y, B, L = job
+        while (st[0] & _lib.ST_REDO) and level < 2:   # climb the ladder: pair -> quad -> exact
+            level = self.engine.note_redo(level)
             with torch.cuda.stream(s):
-                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=_lib.FWD_EXACT, lane=self._lane0 + lane)
+                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=Engine.LEVEL_FLAGS[level], lane=self._lane0 + lane)
             s.synchronize()
-            self.engine.check_status(self._lane0 + lane)
+            st = self.engine.check_status(self._lane0 + lane)
 
     def lane_of(self, slot: int) -> int:
         """Engine lane (status words, workspace) of in-flight slot `slot`."""
