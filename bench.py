@@ -16,7 +16,7 @@ the reference computes for that batch, SURVEY.md §8e mode B), no data-path coll
 An RCCL all_gather of the outputs is exercised once outside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt), with `roofline` for the recurrence
-kernel (timed in situ with HIP events on the launch stream) and `cpu_baseline` (the scalar C oracle
+kernel (timed in situ with HIP events attached to its launches) and `cpu_baseline` (the scalar C oracle
 on the host cores; a reported baseline, not the thing measured).
 """
 from __future__ import annotations
@@ -202,8 +202,9 @@ def main() -> None:
         torch.cuda.synchronize()
 
     def make_events(steps):
-        # one layer's recurrence is bracketed by HIP events per step (rotating over the layers): an event record
-        # costs ~6 us of stream time, so bracketing every layer would inflate the step it measures
+        # one layer's recurrence launch per step carries a pair of HIP events (rotating over the layers): the library
+        # attaches them to the dispatch (hipExtLaunchKernelGGL start/stop events), so elapsed_time() is that launch's
+        # own duration -- the quantity rocprofv3's kernel trace reports -- and nothing extra is enqueued
         events = [[None] * n_ev for _ in range(steps)]
         for k, evs in enumerate(events):
             for j in (2 * (k % nl), 2 * (k % nl) + 1):
@@ -338,7 +339,7 @@ def main() -> None:
                                "(PMC traffic when measured on this workload, else its stream sizes) / the same duration",
                     algorithmic_bytes_per_launch=algo_bytes, stored_bytes_per_launch=stored,
                     moved_gbs=round(moved / scan_avg_s / 1e9, 1), moved_frac=round(moved / scan_avg_s / 1e9 / HBM_PEAK_GBS, 4),
-                    measured=("HIP events around every launch, one layer per step, " +
+                    measured=("HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per step, " +
                               ("in the one-at-a-time pass of the same K steps" if depth > 1 else "in the timed region")),
                     avg_kernel_us_sharing_the_gpu=round(scan_inflight_s * 1e6, 2) if depth > 1 else None)
 

@@ -222,8 +222,10 @@ typedef int (*s5fxp_allreduce_max_fn)(void *ctx, float *dev_vals, int n, void *s
 typedef struct {
     s5fxp_allreduce_max_fn allreduce; /* NULL: per-shard exponents */
     void *allreduce_ctx;
-    /* Measurement only: 2*n_layers hipEvent_t handles (or NULL); events [2l] / [2l+1] are recorded on
-     * `stream` immediately before / after layer l's recurrence kernel(s). NULL entries are skipped. */
+    /* Measurement only: 2*n_layers hipEvent_t handles (or NULL).  Fused path: events [2l] / [2l+1] are attached to
+     * layer l's recurrence launch (hipExtLaunchKernelGGL start / stop events: the time stamps of that dispatch, as
+     * rocprofv3's kernel trace reports them); both must be set.  Generic path: recorded on `stream` immediately
+     * before / after the layer's recurrence kernel.  NULL entries are skipped. */
     void **scan_events;
     int32_t flags; /* S5FXP_FWD_* */
     /* Streaming (sparseRNNs/fxpmodel.py:147-172: the step function's carry is an explicit argument; the reference's

@@ -6,6 +6,8 @@
 #include "s5fxp_kernels.hpp"
 #include "mfma_fused.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

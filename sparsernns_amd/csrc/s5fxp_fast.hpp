@@ -425,30 +425,46 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const int32_t *x0_re = state_in ? state_in + (size_t)li * 2 * plane : nullptr, *x0_im = state_in ? x0_re + plane : nullptr;
         int32_t xmax = 32767; // the C projection's 16-bit planes
         hipStream_t sst = st; // the stream the recurrence runs on
-        if (scan_events && scan_events[2 * li] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li], sst)))) return rc;
+        // measurement: the two events are attached to the launch itself (start / stop time stamps of this dispatch,
+        // what rocprofv3's kernel trace reports), not recorded around it
+        hipEvent_t ev0 = scan_events ? (hipEvent_t)scan_events[2 * li] : nullptr, ev1 = scan_events ? (hipEvent_t)scan_events[2 * li + 1] : nullptr;
+        auto launch_scan = [&](auto kernel, dim3 grid, dim3 block, auto args) {
+            if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, grid, block, 0, sst, ev0, ev1, 0, args);
+            else hipLaunchKernelGGL(kernel, grid, block, 0, sst, args);
+        };
         if (pairl) {
             ScanPairLArgs q{};
             q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
-            // one helper wave: a second one lands on the computing wave's half of the CU's LDS store path and costs more
-            // than it helps (tools/ubench_pair: 44.2 vs 42.8 us); S5FXP_PAIRL_HELPERS2=1 keeps the variant reachable
-            static const bool two_helpers = std::getenv("S5FXP_PAIRL_HELPERS2") != nullptr;
-            if (two_helpers) hipLaunchKernelGGL(k_scan_pairl_asm<2>, dim3((unsigned)((int64_t)B * (P / 32))), dim3(192), 0, sst, q);
-            else hipLaunchKernelGGL(k_scan_pairl_asm<1>, dim3((unsigned)((int64_t)B * (P / 32))), dim3(128), 0, sst, q);
+            // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
+            // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
+            static const int blocks = [] { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); return e && std::atoi(e) == 16 ? 16 : 32; }();
+            const dim3 sgrid((unsigned)((int64_t)B * (P / 32)));
+            auto launch_pairl = [&](auto kernel, int smem_bytes) {
+                static bool attr_set = false; // > 64 KB of dynamic LDS needs the attribute once per kernel
+                if (smem_bytes > 65536 && !attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+                    attr_set = true;
+                }
+                if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, ev0, ev1, 0, q);
+                else hipLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, q);
+            };
+            if (blocks == 16) launch_pairl(k_scan_pairl_asm<16>, 3 * 16 * 1024);
+            else launch_pairl(k_scan_pairl_asm<32>, 3 * 32 * 1024);
             xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax;
         } else if (pair) {
             ScanPairArgs q{};
             q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
-            hipLaunchKernelGGL(k_scan_pair_asm, dim3((unsigned)((int64_t)B * (P / 32))), dim3(64), 0, sst, q);
+            launch_scan(k_scan_pair_asm, dim3((unsigned)((int64_t)B * (P / 32))), dim3(64), q);
             xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax; // <= 32766: a saturated int16 state fails the check
         } else if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             {
-                if (s16) hipLaunchKernelGGL(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
-                else hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, sst, q);
+                if (s16) launch_scan(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
+                else launch_scan(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
             }
             xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
             if (s16 && xmax > 32766) xmax = 32766; // a saturated int16 state must fail the check
@@ -457,9 +473,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = nullptr; q.x0_re = x0_re; q.x0_im = x0_im;
-            hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+            launch_scan(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
         }
-        if (scan_events && scan_events[2 * li + 1] && (rc = hip_rc(hipEventRecord((hipEvent_t)scan_events[2 * li + 1], sst)))) return rc;
         if (!stage_ok("recurrence", li)) return S5FXP_EHIP;
         // ---- fused C projection + D*u + ReLU + out2 + sigmoid + gate (+ range check, + residual maxima)
         GateMArgs ga{};

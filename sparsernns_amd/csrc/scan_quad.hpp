@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // The same pair recurrence fed from LDS: workgroup = the computing wave + a HELPER wave on another SIMD of the CU.
 // The helper streams the layer's Bu as int16 (half the bytes of the int32 K stream), expands K = (Bu << 16) + k and
-// writes it where the computing wave's ds_read_b128 expects it; three LDS buffers of S5_SCANPL_BLOCKS blocks rotate,
+// writes it where the computing wave's ds_read_b128 expects it; three LDS buffers of BLOCKS time blocks rotate,
 // one s_barrier per buffer.  The computing wave's loop is tools/gen_scan_asm.py "pairl".
 //
 // Bu stream ("pair16-native", written by k_bproj_p<.., SM = 3>): per wave run (b, state group of 32), per PAIR of
@@ -367,73 +367,85 @@ struct ScanPairLArgs {
     const int16_t *b16;         // pair16-native Bu stream (already shifted to the state exponent)
     int16_t *xs;                // pair-native packed states
     const int32_t *a_re, *a_im; // (P)
-    int32_t B, TB, P;           // TB % S5_SCANPL_BLOCKS == 0
+    int32_t B, TB, P;           // TB % BLOCKS == 0 (k_scan_pairl_asm<BLOCKS>)
     int32_t ea_re, ea_im;
-    int32_t dbg;                // tools/ubench_pair.hip only: 1 = the helper skips its loads, 2 = it only meets the barriers
     const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
 };
 
-template <int NHELP> // helper waves per workgroup (1 or 2): each expands an equal share of every iteration's blocks
-__global__ __launch_bounds__(64 * (1 + NHELP)) void k_scan_pairl_asm(ScanPairLArgs a)
+template <int... J, class F>
+__device__ __forceinline__ void for_items(std::integer_sequence<int, J...>, F f)
 {
-    __shared__ __attribute__((aligned(16))) int32_t kbuf[3 * S5_SCANPL_BUF / 4];
+    (f(std::integral_constant<int, J>{}), ...);
+}
+
+// DBG (tools/ubench_pair.hip only): 1 = the helper skips its loads, 2 = it only meets the barriers
+template <int BLOCKS, int DBG = 0> // time blocks per LDS buffer (16 or 32): one s_barrier per BLOCKS * 4 steps; 3 * BLOCKS KB of dynamic LDS
+__global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t kbuf[]; // three buffers of BLOCKS KB
+    constexpr int BUFW = BLOCKS * 256;                              // words per buffer
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: recurrence, 1: helper
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);         // (b, state group of 32)
-    const int n_it = a.TB / S5_SCANPL_BLOCKS;
+    const int n_it = a.TB / BLOCKS;
     const int sre = 16 - a.ea_re;
     const bool laneB = lane & 1;
     if (role >= 1) {
         // ---- helper: iteration k+2 goes into buffer (k+2) % 3 while the recurrence works on k
-        constexpr int ALLP = S5_SCANPL_BLOCKS / 2, PAIRS = ALLP / NHELP; // 16-byte items per lane and iteration: all / mine
-        const int j0 = (role - 1) * PAIRS;
-        const i32x4 *src = reinterpret_cast<const i32x4 *>(a.b16) + ((size_t)wave * (a.TB >> 1) + j0) * 64 + lane;
+        constexpr int ITEMS = BLOCKS / 2, NSETS = 32 / ITEMS; // 16-byte items per lane and iteration; register sets
+        static_assert(ITEMS == 8 || ITEMS == 16, "the asm below moves eight 16-byte items per lane at a time");
+        const i32x4 *src = reinterpret_cast<const i32x4 *>(a.b16) + (size_t)wave * (a.TB >> 1) * 64 + lane;
         const int32_t k_re = 65536 - (1 << sre);
         const int32_t kE = laneB ? k_re : 0, kO = laneB ? 0 : k_re; // even steps: lane B computes re' (which carries k)
-        // Four register sets: the loads of an iteration are issued four rounds (~2.5 us of recurrence) before they are used.
-        // The loads and their waits are spelled in asm: across this loop's back edge the compiler's vmcnt bookkeeping
-        // falls back to "wait for everything", which puts a whole HBM latency into every round (ubench_pair: 59 us
-        // instead of 40).  Loads return in order, every step issues exactly PAIRS loads after waiting for the oldest
-        // set, so "all but the youngest 3 * PAIRS" is precisely that set.  Past the end the last iteration is
-        // re-read and expanded into a buffer nobody reads any more: no conditional memory instruction anywhere.
-        static_assert(ALLP == 8 && (NHELP == 1 || NHELP == 2), "asm below moves eight or four 16-byte items per lane and iteration");
-        i32x4 r0[PAIRS], r1[PAIRS], r2[PAIRS], r3[PAIRS];
-        auto fetch = [&](i32x4(&r)[PAIRS], int it) {
-            it = it < n_it ? it : n_it - 1;
-            const i32x4 *ptr = src + ((size_t)it * ALLP + 4) * 64; // +-4 KB immediate offsets around the middle
-            if constexpr (NHELP == 2) {
-                if (a.dbg == 0)
-                    asm volatile("global_load_dwordx4 %0, %4, off offset:-4096 nt\n\tglobal_load_dwordx4 %1, %4, off offset:-3072 nt\n\t"
-                                 "global_load_dwordx4 %2, %4, off offset:-2048 nt\n\tglobal_load_dwordx4 %3, %4, off offset:-1024 nt"
-                                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
-                                 : "v"(ptr)
-                                 : "memory");
-            } else if (a.dbg == 0)
+        // 32 items (128 registers) of loads are in flight, as NSETS sets: the loads of an iteration are issued ~256 steps
+        // (~2.5 us of recurrence) before they are used.  The loads and their waits are spelled in asm: across this
+        // loop's back edge the compiler's vmcnt bookkeeping falls back to "wait for everything", which puts a whole HBM
+        // latency into every round (ubench_pair: 59 us instead of 40).  Loads return in order, every round issues
+        // exactly ITEMS loads after waiting for the oldest set, so "all but the youngest (NSETS - 1) * ITEMS" is
+        // precisely that set.  Past the end the last iteration is re-read and expanded into a buffer nobody reads any
+        // more: no conditional memory instruction anywhere.
+        i32x4 r[NSETS][ITEMS];
+        auto fetch8 = [&](i32x4 *q, const i32x4 *ptr) { // eight items, +-4 KB immediate offsets around ptr
+            if constexpr (DBG == 0)
                 asm volatile("global_load_dwordx4 %0, %8, off offset:-4096 nt\n\tglobal_load_dwordx4 %1, %8, off offset:-3072 nt\n\t"
                              "global_load_dwordx4 %2, %8, off offset:-2048 nt\n\tglobal_load_dwordx4 %3, %8, off offset:-1024 nt\n\t"
                              "global_load_dwordx4 %4, %8, off nt\n\tglobal_load_dwordx4 %5, %8, off offset:1024 nt\n\t"
                              "global_load_dwordx4 %6, %8, off offset:2048 nt\n\tglobal_load_dwordx4 %7, %8, off offset:3072 nt"
-                             : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                             : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
                              : "v"(ptr)
                              : "memory");
         };
-        auto ready = [&](i32x4(&r)[PAIRS]) { // the oldest of the four sets has landed
-            if constexpr (NHELP == 2)
-                asm volatile("s_waitcnt vmcnt(12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
-            else
+        auto fetch = [&](i32x4(&q)[ITEMS], int it) {
+            it = it < n_it ? it : n_it - 1;
+            const i32x4 *ptr = src + ((size_t)it * ITEMS + 4) * 64;
+            fetch8(q, ptr);
+            if constexpr (ITEMS == 16) fetch8(q + 8, ptr + 8 * 64);
+        };
+        auto ready = [&](i32x4(&q)[ITEMS]) { // the oldest set has landed
+            if constexpr (ITEMS == 8)
                 asm volatile("s_waitcnt vmcnt(24)"
-                             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                             : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
                              :
                              : "memory");
+            else {
+                asm volatile("s_waitcnt vmcnt(16)"
+                             : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
+                             :
+                             : "memory");
+                asm volatile(""
+                             : "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15])
+                             :
+                             : "memory");
+            }
         };
-        auto expand = [&](const i32x4(&r)[PAIRS], int it) {
-            if (a.dbg == 2) return;
-            int32_t *dst = kbuf + (it % 3) * (S5_SCANPL_BUF / 4) + j0 * 512 + lane * 4;
+        auto expand = [&](const i32x4(&q)[ITEMS], int it) {
+            if constexpr (DBG == 2) return;
+            int32_t *dst = kbuf + (it % 3) * BUFW + lane * 4;
 #pragma unroll
-            for (int j = 0; j < PAIRS; ++j) {
+            for (int j = 0; j < ITEMS; ++j) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) { // [t0 t2 | t1 t3] halfword pairs of block 2j + h
-                    const uint32_t d0 = (uint32_t)r[j][2 * h], d1 = (uint32_t)r[j][2 * h + 1];
+                    const uint32_t d0 = (uint32_t)q[j][2 * h], d1 = (uint32_t)q[j][2 * h + 1];
                     i32x4 k;
                     k[0] = (int)((d0 << 16) + (uint32_t)kE);
                     k[1] = (int)((d0 & 0xffff0000u) | (uint32_t)kE);
@@ -443,26 +455,67 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void k_scan_pairl_asm(ScanPairLAr
                 }
             }
         };
-        auto meet = [&]() {
-            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the LDS writes have landed
-            __builtin_amdgcn_s_barrier();
+        auto meet = [&]() { // the LDS writes have landed (the clobber keeps the compiler from sinking them below the barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
 #pragma unroll
-        for (int j = 0; j < PAIRS; ++j) r0[j] = r1[j] = r2[j] = r3[j] = i32x4{0, 0, 0, 0};
-        fetch(r0, 0); fetch(r1, 1); fetch(r2, 2); fetch(r3, 3);
-        ready(r0); expand(r0, 0); fetch(r0, 4);
-        ready(r1); expand(r1, 1); fetch(r1, 5);
+        for (int s = 0; s < NSETS; ++s) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) r[s][j] = i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) fetch(r[s], s);
+        ready(r[0]); expand(r[0], 0); fetch(r[0], NSETS);
+        ready(r[1]); expand(r[1], 1); fetch(r[1], NSETS + 1);
         meet();
-        // round k (the recurrence works on iteration k): iteration k+2 goes into LDS from set (k+2) % 4, which then
-        // receives iteration k+6
-        for (int k = 0; k < n_it; k += 4) {
-            ready(r2); expand(r2, k + 2); fetch(r2, k + 6); meet();
-            if (k + 1 >= n_it) break;
-            ready(r3); expand(r3, k + 3); fetch(r3, k + 7); meet();
-            if (k + 2 >= n_it) break;
-            ready(r0); expand(r0, k + 4); fetch(r0, k + 8); meet();
-            if (k + 3 >= n_it) break;
-            ready(r1); expand(r1, k + 5); fetch(r1, k + 9); meet();
+        // round k (the recurrence works on iteration k): iteration k+2 goes into LDS from set (k+2) % NSETS, which then
+        // receives iteration k+2+NSETS
+        // One round, item by item: expand item j of the set that has landed (two ds_write_b128), refill its registers with
+        // item j of the iteration NSETS rounds ahead.  (Tried and measured in tools/ubench_pair, all within 0.2 us of this:
+        // bursts instead of item-by-item; an s_sleep after every item -- 2 x 64 clocks already starves the recurrence;
+        // the helper as wave 2 or 3 of the workgroup -- wave 2 shares the computing wave's LDS path: +1.7 us; extra waves
+        // that share the fill of the first two buffers.  What this wave costs the computing one, +3 us over a helper that
+        // only meets the barriers, is the LDS writes and the loads themselves, half each.)
+        auto round = [&](i32x4(&q)[ITEMS], int kk) {
+            ready(q);
+            int itf = kk + 2 + NSETS;
+            itf = itf < n_it ? itf : n_it - 1;
+            const i32x4 *ptr = src + ((size_t)itf * ITEMS + 4) * 64;
+            int32_t *dst = kbuf + ((kk + 2) % 3) * BUFW + lane * 4;
+            for_items(std::make_integer_sequence<int, ITEMS>{}, [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (DBG != 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t d0 = (uint32_t)q[j][2 * h], d1 = (uint32_t)q[j][2 * h + 1];
+                        i32x4 k;
+                        k[0] = (int)((d0 << 16) + (uint32_t)kE);
+                        k[1] = (int)((d0 & 0xffff0000u) | (uint32_t)kE);
+                        k[2] = (int)((d1 << 16) + (uint32_t)kO);
+                        k[3] = (int)((d1 & 0xffff0000u) | (uint32_t)kO);
+                        *reinterpret_cast<i32x4 *>(dst + (2 * j + h) * 256) = k;
+                    }
+                }
+                const i32x4 *pj = ptr + (j / 8) * 8 * 64; // +-4 KB immediate offsets around it
+                if constexpr (DBG == 0)
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=&v"(q[j]) : "v"(pj), "n"((j % 8 - 4) * 1024) : "memory");
+            });
+            meet();
+        };
+        for (int k = 0; k < n_it; k += NSETS) {
+            if constexpr (NSETS == 4) {
+                round(r[2], k);
+                if (k + 1 >= n_it) break;
+                round(r[3], k + 1);
+                if (k + 2 >= n_it) break;
+                round(r[0], k + 2);
+                if (k + 3 >= n_it) break;
+                round(r[1], k + 3);
+            } else {
+                round(r[0], k);
+                if (k + 1 >= n_it) break;
+                round(r[1], k + 1);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may still be landing in registers when the wave ends
         return;
@@ -479,11 +532,18 @@ __global__ __launch_bounds__(64 * (1 + NHELP)) void k_scan_pairl_asm(ScanPairLAr
     const int32_t x0 = a.x0_re ? (laneB ? a.x0_im[sp] : a.x0_re[sp]) : 0; // lane A holds re before an even step
 
     unsigned cnt = (unsigned)n_it;
-    asm volatile(S5_SCANPL_ASM_BODY
-                 : [cnt] "+s"(cnt)
-                 : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vlds] "v"(vlds), [vout] "v"(vout),
-                   [x0] "v"(x0), [pout] "s"(pout)
-                 : S5_SCANPL_ASM_CLOBBERS);
+    if constexpr (BLOCKS == 16)
+        asm volatile(S5_SCANPL16_ASM_BODY
+                     : [cnt] "+s"(cnt)
+                     : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vlds] "v"(vlds), [vout] "v"(vout),
+                       [x0] "v"(x0), [pout] "s"(pout)
+                     : S5_SCANPL16_ASM_CLOBBERS);
+    else
+        asm volatile(S5_SCANPL32_ASM_BODY
+                     : [cnt] "+s"(cnt)
+                     : [coe] "v"(coe), [cpe] "v"(cpe), [coo] "v"(coo), [cpo] "v"(cpo), [vlds] "v"(vlds), [vout] "v"(vout),
+                       [x0] "v"(x0), [pout] "s"(pout)
+                     : S5_SCANPL32_ASM_CLOBBERS);
 }
 
 } // namespace s5

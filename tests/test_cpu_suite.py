@@ -383,7 +383,7 @@ def test_generated_scan_asm_is_up_to_date(tmp_path):
     t16, _ = gen.emit("S5_SCAN16_ASM", gen.Plan(True))
     t32w, _ = gen.emit("S5_SCAN32W_ASM", gen.Plan(False, wide=True))
     tp, _ = gen.emit_pair()
-    tpl, _ = gen.emit_pairl()
+    tpl = "".join(gen.emit_pairl(D, f"S5_SCANPL{D}_ASM")[0] for D in gen.PAIRL_BLOCKS)
     have = open(os.path.join(ROOT, "sparsernns_amd", "csrc", "scan_quad_asm.inc")).read()
     assert t32 in have and t16 in have and t32w in have and tp in have and tpl in have
     assert f"#define S5_SCAN_ASM_DEPTH {gen.DEPTH}" in have and f"#define S5_SCANP_ASM_DEPTH {gen.PAIR_DEPTH}" in have

@@ -754,11 +754,11 @@ def test_pair_recurrence_kernel_is_selected_and_guarded():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, S5FXP_NO_PAIR="1"))
     assert r.returncode == 0 and "quad16 path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-    # the pair kernel's other feeds: the int32 K stream in global memory, and two helper waves
+    # the pair kernel's other feeds: the int32 K stream in global memory, and the LDS-fed kernel with 16-block buffers
     code2 = code.replace("== 2", "in (3, 4)").replace("quad16 path ok", "pair variant ok")
-    for var in ("S5FXP_PAIR_GLOBAL", "S5FXP_PAIRL_HELPERS2"):
+    for var, val in (("S5FXP_PAIR_GLOBAL", "1"), ("S5FXP_PAIRL_BLOCKS", "16")):
         r = subprocess.run([sys.executable, "-c", code2], cwd=root, capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, **{var: "1"}))
+                           env=dict(os.environ, **{var: val}))
         assert r.returncode == 0 and "pair variant ok" in r.stdout, var + r.stdout[-2000:] + r.stderr[-3000:]
 
 

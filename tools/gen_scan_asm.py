@@ -317,9 +317,8 @@ def emit_pair(name="S5_SCANP_ASM"):
 # One iteration = PAIRL_BLOCKS blocks = one LDS buffer; s_barrier at the end of every iteration; the register ring
 # (PAIRL_RING blocks) prefetches across the iteration boundary, which is why there are three buffers: the helper fills
 # iteration k+2 while this wave works on k and prefetches from k+1.
-PAIRL_BLOCKS = 16
+PAIRL_BLOCKS = (16, 32)           # both are generated: k_scan_pairl_asm<BLOCKS>
 PAIRL_RING = 8
-PAIRL_BUF = PAIRL_BLOCKS * 1024
 
 
 class PairLPlan:
@@ -335,9 +334,10 @@ class PairLPlan:
     LAST = T0
 
 
-def pairl_iteration(first: bool):
+def pairl_iteration(first: bool, D: int):
     Q = PairLPlan
-    D, RD = PAIRL_BLOCKS, PAIRL_RING
+    RD = PAIRL_RING
+    PAIRL_BUF = D * 1024
     out = []
     for i in range(D):
         g, half = i // 2, i % 2
@@ -387,10 +387,11 @@ def pairl_iteration(first: bool):
     return out
 
 
-def pairl_body():
+def pairl_body(D: int):
     Q = PairLPlan
-    D, RD = PAIRL_BLOCKS, PAIRL_RING
-    assert D % RD == 0 and (D // 2) % 8 == 0 or D // 2 == 8
+    RD = PAIRL_RING
+    PAIRL_BUF = D * 1024
+    assert D % RD == 0 and (D // 2) % 8 == 0 and D * 1024 <= 65536 - 1024 * RD
     b = [f"v_mov_b32 v{Q.O + 15}, %[x0]",
          f"v_mov_b32 v{Q.VCUR}, %[vlds]",
          f"v_add_u32 v{Q.VNXT}, {PAIRL_BUF}, v{Q.VCUR}",
@@ -400,9 +401,9 @@ def pairl_body():
     for n in range(RD):
         b.append(f"ds_read_b128 v[{Q.R0 + 4 * n}:{Q.R0 + 4 * n + 3}], v{Q.VCUR} offset:{n * 1024}")
     b.append("s_waitcnt lgkmcnt(0)")
-    b += pairl_iteration(True)
+    b += pairl_iteration(True, D)
     b += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 2f", "1:"]
-    b += pairl_iteration(False)
+    b += pairl_iteration(False, D)
     b += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b", "2:"]
     last_g = D // 2 - 1
     o, pk = Q.O + 8 * (last_g & 1), Q.PK + 4 * (last_g & 1)
@@ -413,8 +414,8 @@ def pairl_body():
     return b
 
 
-def emit_pairl(name="S5_SCANPL_ASM"):
-    b = pairl_body()
+def emit_pairl(D, name):
+    b = pairl_body(D)
     clobbers = ", ".join(f'"v{r}"' for r in range(PairLPlan.R0, PairLPlan.LAST + 1))
     text = "\n".join(f'    "{l}\\n\\t"' for l in b)
     return (f"#define {name}_BODY \\\n{text.replace(chr(10), ' ' + chr(92) + chr(10))}\n"
@@ -434,7 +435,11 @@ def main():
     t16, n16 = emit("S5_SCAN16_ASM", Plan(True))
     t32w, n32w = emit("S5_SCAN32W_ASM", Plan(False, wide=True))
     tp, npair = emit_pair()
-    tpl, npairl = emit_pairl()
+    tpl, npairl = "", []
+    for D in PAIRL_BLOCKS:
+        t, n = emit_pairl(D, f"S5_SCANPL{D}_ASM")
+        tpl += t
+        npairl.append(n)
     out = f"""// GENERATED by tools/gen_scan_asm.py -- do not edit.  DEPTH = {DEPTH}.
 // Operands: [ca] [cb] [ka] [kb] [voff] [x0] VGPR inputs; [rin] [rout] 128-bit SGPR buffer descriptors;
 // [stride] SGPR bytes per time block; [sld] [sst] [cnt] SGPR read-write (load / store offsets, iterations).
@@ -445,10 +450,8 @@ def main():
 // wave's run of the K stream / the packed state stream; [cnt] SGPR read-write (iterations of {PAIR_DEPTH} blocks).
 #define S5_SCAN_ASM_DEPTH {DEPTH}
 // S5_SCANPL_ASM_BODY (pair kernel fed from LDS): [vlds] = lane * 16 (byte address in LDS buffer 0) instead of [vin] / [pin];
-// {PAIRL_BLOCKS} blocks per iteration and LDS buffer, three buffers of {PAIRL_BUF} bytes, one s_barrier per iteration (+ one up front).
+// S5_SCANPL<D>_ASM_BODY: D blocks per iteration and LDS buffer, three buffers of D KB, one s_barrier per iteration (+ one up front).
 #define S5_SCANP_ASM_DEPTH {PAIR_DEPTH}
-#define S5_SCANPL_BLOCKS {PAIRL_BLOCKS}
-#define S5_SCANPL_BUF {PAIRL_BUF}
 {t32}{t16}{t32w}{tp}{tpl}"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sparsernns_amd", "csrc", "scan_quad_asm.inc")
     with open(path, "w") as f:

@@ -26,7 +26,7 @@ double time_us(F launch, int reps = 20)
 
 int main(int argc, char **argv)
 {
-    const int B = argc > 1 ? atoi(argv[1]) : 32, P = 64, L = 4096, TB = L / 4, PG = P / 32;
+    const int B = argc > 1 ? atoi(argv[1]) : 32, P = 64, L = argc > 2 ? atoi(argv[2]) : 4096, TB = L / 4, PG = P / 32;
     const int ea = 15, k_re = 65536 - 2;
     const size_t runs = (size_t)B * PG, kwords = runs * TB * 256, halves = runs * TB * 256;
     std::vector<int32_t> K(kwords + 64 * 256), ar(P), ai(P);
@@ -50,24 +50,26 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dK, K.data(), K.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db16, b16.data(), b16.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dar, ar.data(), P * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dai, ai.data(), P * 4, hipMemcpyHostToDevice));
     ScanPairArgs g{dK, dxs1, dar, dai, B, TB, P, ea, ea};
-    ScanPairLArgs l{db16, dxs2, dar, dai, B, TB, P, ea, ea, 0};
+    ScanPairLArgs l{db16, dxs2, dar, dai, B, TB, P, ea, ea};
     const double algo = (double)B * L * P * 16;
     auto report = [&](const char *name, double us) { printf("%-44s %8.2f us  %6.2f ns/step  %.3f of 8 TB/s (16*P B/frame)\n", name, us, us * 1e3 / L, algo / (us * 1e-6) / 8e12); };
     report("pair, K int32 from global", time_us([&] { hipLaunchKernelGGL(k_scan_pair_asm, dim3(runs), dim3(64), 0, 0, g); }));
-    report("pair, LDS-fed, 2 helper waves", time_us([&] { hipLaunchKernelGGL(k_scan_pairl_asm<2>, dim3(runs), dim3(192), 0, 0, l); }));
-    report("pair, LDS-fed (helper wave, int16 Bu)", time_us([&] { hipLaunchKernelGGL(k_scan_pairl_asm<1>, dim3(runs), dim3(128), 0, 0, l); }));
+#define L16(D) [&] { hipLaunchKernelGGL((k_scan_pairl_asm<16, D>), dim3(runs), dim3(128), 48 * 1024, 0, l); }
+#define L32(D) [&] { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pairl_asm<32, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+                     hipLaunchKernelGGL((k_scan_pairl_asm<32, D>), dim3(runs), dim3(128), 96 * 1024, 0, l); }
+    auto l16 = L16(0);
+    auto l32 = L32(0);
     std::vector<int16_t> x1(halves), x2(halves);
-    CK(hipMemcpy(x1.data(), dxs1, halves * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(x2.data(), dxs2, halves * 2, hipMemcpyDeviceToHost));
-    size_t bad = 0; for (size_t i = 0; i < halves; ++i) bad += x1[i] != x2[i];
-    printf("global-K vs LDS-fed outputs: %zu mismatches of %zu\n", bad, halves);
-    l.dbg = 1; report("  LDS-fed, helper without loads", time_us([&] { hipLaunchKernelGGL(k_scan_pairl_asm<1>, dim3(runs), dim3(128), 0, 0, l); }));
-    l.dbg = 2; report("  LDS-fed, helper only meets the barriers", time_us([&] { hipLaunchKernelGGL(k_scan_pairl_asm<1>, dim3(runs), dim3(128), 0, 0, l); }));
-    l.dbg = 0;
-    CK(hipMemset(dxs2, 0, halves * 2));
-    hipLaunchKernelGGL(k_scan_pairl_asm<2>, dim3(runs), dim3(192), 0, 0, l);
-    CK(hipMemcpy(x2.data(), dxs2, halves * 2, hipMemcpyDeviceToHost));
-    bad = 0; for (size_t i = 0; i < halves; ++i) bad += x1[i] != x2[i];
-    printf("global-K vs LDS-fed (2 helpers) outputs: %zu mismatches of %zu\n", bad, halves);
-    l.dbg = 2; report("  LDS-fed 2 helpers, barriers only", time_us([&] { hipLaunchKernelGGL(k_scan_pairl_asm<2>, dim3(runs), dim3(192), 0, 0, l); }));
+    CK(hipMemcpy(x1.data(), dxs1, halves * 2, hipMemcpyDeviceToHost));
+    auto check = [&](const char *name) {
+        CK(hipMemcpy(x2.data(), dxs2, halves * 2, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < halves; ++i) bad += x1[i] != x2[i];
+        printf("global-K vs %s outputs: %zu mismatches of %zu\n", name, bad, halves);
+        CK(hipMemset(dxs2, 0, halves * 2));
+    };
+    report("pair, LDS-fed, 16 blocks per buffer", time_us(l16)); check("LDS-fed/16");
+    report("pair, LDS-fed, 32 blocks per buffer", time_us(l32)); check("LDS-fed/32");
+    report("  /16, helper without loads", time_us(L16(1))); report("  /32, helper without loads", time_us(L32(1)));
+    report("  /16, helper only meets the barriers", time_us(L16(2))); report("  /32, helper only meets the barriers", time_us(L32(2)));
     return 0;
 }
