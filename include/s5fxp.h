@@ -106,6 +106,17 @@ int s5fxp_scan(const int32_t *bu_re, const int32_t *bu_im, const int32_t *a_re, 
                int32_t *xs_im, int B, int L, int P, int a_re_exp, int a_im_exp, int bu_re_exp, int bu_im_exp,
                int x_re_exp, int x_im_exp, int flags, void *stream);
 
+/* The FLOAT model's diagonal-SSM scan, sparseRNNs/model/ssm.py:54-77 (binary operator) + :127
+ * (jax.lax.associative_scan over (Lambda_elements, Bu_elements); :166-168 reverse=True for the bidirectional half;
+ * vmapped over the batch by the caller of _apply_ssm).  x_t = lambda * x_{t-1} + bu_t in complex64, evaluated as a
+ * time-parallel prefix (segment folds, __shfl_up + LDS sweeps over the segment aggregates).  Floating-point prefix sums
+ * depend on the combination tree: results agree with the reference's to rounding (tests/: |err| <= 1e-5 * max|x|), not bit
+ * for bit.  lambda: (P) complex64 (re, im interleaved); bu, xs: (B,L,P) complex64; x0: (B,P) state before the first
+ * step or NULL (zeros -- the reference's scan has no initial element); x_last: (B,P) state after the last step, or NULL.
+ * reverse != 0 scans from t = L-1 down to 0. */
+int s5fxp_assoc_scan_c64(const float *lambda, const float *bu, float *xs, const float *x0, float *x_last, int B, int L,
+                         int P, int reverse, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Model level: FxpRegressionModel.forward, fxpmodel.py:1431-1439 (-> 1261-1271 -> 1110-1161).
  * The integer parameters are what FxpRegressionModel.export() emits

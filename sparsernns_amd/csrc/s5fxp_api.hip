@@ -5,6 +5,7 @@
 #include "../../include/s5fxp.h"
 #include "s5fxp_kernels.hpp"
 #include "mfma_fused.hpp"
+#include "scan_assoc.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -257,6 +258,21 @@ extern "C" int s5fxp_scan(const int32_t *bu_re, const int32_t *bu_im, const int3
     a.B = B; a.L = L; a.P = P; a.TB = 0; a.ea_re = a_re_exp; a.ea_im = a_im_exp; a.sh_re = sr; a.sh_im = si;
     a.relu = flags & 1; a.run_if = nullptr;
     return launch_scan(a, S(stream));
+}
+
+extern "C" int s5fxp_assoc_scan_c64(const float *lambda, const float *bu, float *xs, const float *x0, float *x_last, int B,
+                                    int L, int P, int reverse, void *stream)
+{
+    if (!lambda || !bu || !xs || B < 0 || L < 0 || P < 1) return S5FXP_EBADARG;
+    if (B == 0 || L == 0) return S5FXP_OK;
+    const int64_t grid = (int64_t)B * ((P + ASSOC_PT - 1) / ASSOC_PT);
+    if (grid > 0x7fffffffll) return S5FXP_EBADARG;
+    ScanAssocArgs a{};
+    a.lambda = reinterpret_cast<const float2 *>(lambda); a.bu = reinterpret_cast<const float2 *>(bu);
+    a.xs = reinterpret_cast<float2 *>(xs); a.x0 = reinterpret_cast<const float2 *>(x0);
+    a.x_last = reinterpret_cast<float2 *>(x_last); a.B = B; a.L = L; a.P = P; a.reverse = reverse ? 1 : 0;
+    hipLaunchKernelGGL(k_scan_assoc_c64, dim3((unsigned)grid), dim3(64 * ASSOC_WAVES), 0, S(stream), a);
+    return launch_rc();
 }
 
 // -----------------------------------------------------------------------------------------------
