@@ -18,6 +18,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 SCALES = [float(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0.3, 1.0, 1.0, 2.5, 6.0]
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
+rungs = {}
 t0 = time.time()
 for case in range(n_cases):
     dim = float(rng.choice([0.5, 0.5, 0.5, 1.0]))
@@ -60,7 +61,10 @@ for case in range(n_cases):
             print(f"MISMATCH case {case}.{j}: dim={dim} B={B} L={L} scale={scale} cfg={cfg} "
                   f"diff={np.count_nonzero(y.cpu().numpy() != ref)}")
     st = int(eng.status[0].item())
+    rung = ("pair", "quad16", "exact")[eng.level]
+    rungs[rung] = rungs.get(rung, 0) + 1
     print(f"case {case}: dim={dim} B={B} L={L} scale={scale} sparsity={cfg['sparsity']} fast={bool(_lib.lib.s5fxp_model_is_fast(eng._h))} "
-          f"status=0x{st:x} ok   [{time.time() - t0:.0f}s]", flush=True)
+          f"recurrence rung after the case={rung} status=0x{st:x} ok   [{time.time() - t0:.0f}s]", flush=True)
+print("cases that ended on each recurrence rung:", rungs)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
