@@ -580,6 +580,31 @@ def test_baseline_configs_at_full_size_match_oracle(name):
     assert (y1.bits, y1.exp) == (rb, re_) and np.array_equal(y1.numpy(), cm.forward(fx.data, fx.bits, fx.exp)[0])
 
 
+@pytest.mark.parametrize("B,L", [(1, 16388), (3, 8196), (5, 132)])
+def test_long_and_ragged_sequences_on_every_rung(B, L):
+    """Sequence lengths that are not multiples of the recurrence kernels' 128-step buffers or 32-block rings (the streams
+    are padded, the tail blocks must not leak into real frames), four times the bench length, odd batch sizes -- on the
+    pair rung, on the quad16 rung (S5FXP_FWD_NO_PAIR) and on the exact kernels."""
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5, calib_L=256, state_headroom_bits=1))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    fx = _input(qc, dims, B, L, seed=77)
+    ref = cm.forward(fx.data, fx.bits, fx.exp)[0]
+    import torch
+    x = torch.from_numpy(fx.data).cuda()
+    for flags in (_lib.FWD_DEFER_REDO, _lib.FWD_DEFER_REDO | _lib.FWD_NO_PAIR, _lib.FWD_EXACT, 0):
+        y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+        eng.enqueue(x, fx.bits, fx.exp, y, B, L, flags=flags)
+        torch.cuda.synchronize()
+        assert not (int(eng.status[0].item()) & _lib.ST_REDO), f"flags {flags}: the calibrated model should stay in range"
+        assert np.array_equal(y.cpu().numpy(), ref), f"flags {flags}"
+
+
 def test_w4a8_tracks_w8a16_within_the_stated_tolerance():
     """BASELINE configs[4]: "tolerance-checked vs w8a16".  The same float model and input, quantised with both recipes,
     both run on the GPU (each bit-exact against its own oracle run: the test above and this one), outputs decoded to
