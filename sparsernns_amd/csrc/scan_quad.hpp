@@ -407,10 +407,10 @@ __global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a)
         i32x4 r[NSETS][ITEMS];
         auto fetch8 = [&](i32x4 *q, const i32x4 *ptr) { // eight items, +-4 KB immediate offsets around ptr
             if constexpr (DBG == 0)
-                asm volatile("global_load_dwordx4 %0, %8, off offset:-4096 nt\n\tglobal_load_dwordx4 %1, %8, off offset:-3072 nt\n\t"
-                             "global_load_dwordx4 %2, %8, off offset:-2048 nt\n\tglobal_load_dwordx4 %3, %8, off offset:-1024 nt\n\t"
-                             "global_load_dwordx4 %4, %8, off nt\n\tglobal_load_dwordx4 %5, %8, off offset:1024 nt\n\t"
-                             "global_load_dwordx4 %6, %8, off offset:2048 nt\n\tglobal_load_dwordx4 %7, %8, off offset:3072 nt"
+                asm volatile("global_load_dwordx4 %0, %8, off offset:-4096\n\tglobal_load_dwordx4 %1, %8, off offset:-3072\n\t"
+                             "global_load_dwordx4 %2, %8, off offset:-2048\n\tglobal_load_dwordx4 %3, %8, off offset:-1024\n\t"
+                             "global_load_dwordx4 %4, %8, off\n\tglobal_load_dwordx4 %5, %8, off offset:1024\n\t"
+                             "global_load_dwordx4 %6, %8, off offset:2048\n\tglobal_load_dwordx4 %7, %8, off offset:3072"
                              : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
                              : "v"(ptr)
                              : "memory");
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a)
                 }
                 const i32x4 *pj = ptr + (j / 8) * 8 * 64; // +-4 KB immediate offsets around it
                 if constexpr (DBG == 0)
-                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=&v"(q[j]) : "v"(pj), "n"((j % 8 - 4) * 1024) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(q[j]) : "v"(pj), "n"((j % 8 - 4) * 1024) : "memory");
             });
             meet();
         };
