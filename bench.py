@@ -83,8 +83,8 @@ def scan_stored_bytes(kernel: str, algo_bytes: int) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="BASELINE.json configs[i]: 1 = dim 0.5 w8a16 dense, 32 x 4096 per GPU (the headline); 2 = the same "
                          "90 %% pruned; 3 = dim 1.0 pruned, ONE batch of 512 sequences sharded over the ranks + timed "
