@@ -259,24 +259,37 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                  m->layers[li].res_bits <= 16;
     }
 
-    // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles, two workgroups per CU
-    const int64_t tiles64 = (N + 63) / 64, per6 = (tiles64 + 511) / 512;
-    const unsigned grid6 = (unsigned)((tiles64 + per6 - 1) / per6);
+    // workgroups per launch (persistent loops over tiles): tuned per kernel on MI355X (256 CUs), S5FXP_WGS_* override them
+    auto wgs_cap = [](const char *name, int dflt) {
+        const char *e = std::getenv(name);
+        const int v = e ? std::atoi(e) : 0;
+        return (int64_t)(v > 0 ? v : dflt);
+    };
+    static const int64_t cap_enc = wgs_cap("S5FXP_WGS_ENC", 512), cap_dec = wgs_cap("S5FXP_WGS_DEC", 512),
+                         cap_cgate = wgs_cap("S5FXP_WGS_CGATE", 512), cap_bproj = wgs_cap("S5FXP_WGS_BPROJ", 1024),
+                         cap_resid = wgs_cap("S5FXP_WGS_RESID", 512);
+    // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles
+    const int64_t tiles64 = (N + 63) / 64;
+    auto grid_for = [&](int64_t tiles, int64_t cap) {
+        const int64_t per = (tiles + cap - 1) / cap;
+        return (unsigned)((tiles + per - 1) / per);
+    };
+    const unsigned grid_enc = grid_for(tiles64, cap_enc), grid_dec = grid_for(tiles64, cap_dec);
     auto launch6g = [&](auto kernel, unsigned g6, size_t smem, const auto &args, unsigned threads = 384) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kernel, dim3(g6), dim3(threads), smem, st, args);
     };
-    auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid6, smem, args); };
+    auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid_dec, smem, args); };
     auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, const ResidTail &tl) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kernel, dim3(grid6), dim3(384), smem, st, args, ext, tl);
+        hipLaunchKernelGGL(kernel, dim3(grid_enc), dim3(384), smem, st, args, ext, tl);
     };
 
     // residual / extremes pass: a workgroup owns rm_span consecutive frames, a multiple of its 4 x R frame step
     const int64_t rm_step = 4 * (RESID_THREADS / (H / 8)), rm_iters = (N + rm_step - 1) / rm_step;
-    const int64_t rm_per = (rm_iters + 511) / 512, rm_span = rm_per * rm_step;
+    const int64_t rm_per = (rm_iters + cap_resid - 1) / cap_resid, rm_span = rm_per * rm_step;
     const unsigned rm_grid = (unsigned)((rm_iters + rm_per - 1) / rm_per);
 
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
@@ -396,7 +409,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
             {
                 a.t_lo = 0; a.t_len = L;
-                const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? 512 : 1024, per = (tl + cap - 1) / cap;
+                const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? cap_bproj / 2 : cap_bproj, per = (tl + cap - 1) / cap;
                 const unsigned bthr = big ? 512 : 256; // one wave per 32-column tile of [B_re | B_im]
                 const unsigned pgrid = (unsigned)((tl + per - 1) / per);
                 if (tr) {
@@ -523,7 +536,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             } else {
                 {
                     a.t_lo = 0; a.t_len = L;
-                    const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + 511) / 512;
+                    const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + cap_cgate - 1) / cap_cgate;
                     const unsigned cg = (unsigned)((tl + per - 1) / per);
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
