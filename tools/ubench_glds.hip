@@ -101,9 +101,9 @@ double time_us(F launch, int reps = 10)
     return ms * 1e3 / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const long N = 131072;
+    const long N = argc > 1 ? atol(argv[1]) : 131072;
     int *x, *out;
     CK(hipMalloc(&x, (size_t)N * 260 * 4 + 4096)); CK(hipMalloc(&out, 64));
     CK(hipMemset(x, 1, (size_t)N * 260 * 4 + 4096));
