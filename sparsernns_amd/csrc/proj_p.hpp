@@ -15,6 +15,20 @@
 // Planes are double buffered: one barrier per tile, phase A of tile i+1 overlaps phase B of tile i in other
 // waves.  ~30 KB LDS and < 128 registers: four workgroups (16 waves) per CU.
 #pragma once
+// -DS5_PHASE_PROF (tools/prof_phases.py, never in the shipped library): every thread 0 accumulates the shader clock between
+// phase marks of k_enc_p.  A mark first touches a register the preceding work produced (v_mov: the hardware interlock makes
+// it wait for an MFMA or a load that is still in flight -- a bare s_memtime is hoisted over pure arithmetic by the compiler
+// and overtakes pending MFMAs in the hardware), then reads the clock.
+#ifdef S5_PHASE_PROF
+__device__ long long g_phase_prof[2048 * 8];
+#define PHASE_DECL long long prof_last = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); prof_last = t_; }
+#define PHASE_MARK(i, reg) do { long long t_; int d_; asm volatile("v_mov_b32 %1, %2\n\ts_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=v"(d_) : "v"(reg) : "memory"); prof_acc[i] += t_ - prof_last; prof_last = t_; } while (0)
+#define PHASE_DUMP do { if (threadIdx.x == 0 && blockIdx.x < 2048) for (int i_ = 0; i_ < 8; ++i_) g_phase_prof[blockIdx.x * 8 + i_] = prof_acc[i_]; } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i, reg)
+#define PHASE_DUMP
+#endif
 #include "mfma_bn.hpp"
 
 namespace s5 {
@@ -338,16 +352,20 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
     }
     bool wide = false;
     __syncthreads();
+    PHASE_DECL
     for (; tile < tiles; tile += gridDim.x) {
         const int64_t n0 = tile * FT;
+        PHASE_MARK(0, l); // loop top (includes the previous tile's closing barrier)
         // ---- phase A
 #pragma unroll
         for (int i = 0; i < RB; ++i) rawb[i] = *row_ptr(tile, RA + i);
 #pragma unroll
         for (int i = 0; i < RA; ++i) convert_row(rawa[i], wave + NW * i, wide);
+        PHASE_MARK(1, rawa[RA - 1][0]); // prefetched rows converted
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             if (wave + NW * (RA + i) < FT) convert_row(rawb[i], wave + NW * (RA + i), wide);
+        PHASE_MARK(2, rawb[RB - 1][0]); // rows requested at the top (their HBM latency included)
         for (int e = threadIdx.x; e < FT * rem; e += 384) { // the K-256 tail of every row
             const int f = e / rem, k = 256 + e % rem;
             int64_t n = n0 + f;
@@ -361,7 +379,9 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
 #pragma unroll
             for (int i = 0; i < RA; ++i) rawa[i] = *row_ptr(tile + gridDim.x, i); // in flight during phase B
         }
+        PHASE_MARK(3, l); // tail column + prefetch issue
         __syncthreads();
+        PHASE_MARK(4, l); // mid barrier
         // ---- phase B
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -369,6 +389,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
             const int64_t n = n0 + 32 * sub + r;
             v16i acc;
             mfma_planes<KS>(acc, wreg, Xh + (32 * sub + r) * KP + 16 * h, Xl + (32 * sub + r) * KP + 16 * h, cs + ch0);
+            PHASE_MARK(5, acc[15]); // operand reads + MFMA chain, complete
             if (n < a.N) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -391,8 +412,10 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
                 }
             }
         }
+        PHASE_MARK(6, pk[15]); // epilogue arithmetic done, stores issued
         __syncthreads(); // planes are single-buffered
     }
+    PHASE_DUMP;
     if (__any(wide) && l == 0) atomicOr(a.status, ST_WIDE_INPUT);
     if (!ext) return;
     // ---- extremes: fold the 32 frame lanes of each half wave, then the waves of the workgroup (LDS), then one

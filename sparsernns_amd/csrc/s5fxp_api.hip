@@ -764,3 +764,11 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
     }
     return launch_rc();
 }
+
+#ifdef S5_PHASE_PROF
+// tools/prof_phases.py only (a -DS5_PHASE_PROF build): the accumulated phase clocks of k_enc_p
+extern "C" int s5fxp_debug_phase_prof(long long *host_out, int n)
+{
+    return hip_rc(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_prof), (size_t)n * sizeof(long long)));
+}
+#endif
