@@ -16,14 +16,19 @@
 // waves.  ~30 KB LDS and < 128 registers: four workgroups (16 waves) per CU.
 #pragma once
 // -DS5_PHASE_PROF (tools/prof_phases.py, never in the shipped library): every thread 0 accumulates the shader clock between
-// phase marks of k_enc_p.  A mark first touches a register the preceding work produced (v_mov: the hardware interlock makes
+// phase marks of k_enc_p.  A mark first touches a register the preceding work produced (a v_cmp into vcc: the hardware interlock makes
 // it wait for an MFMA or a load that is still in flight -- a bare s_memtime is hoisted over pure arithmetic by the compiler
 // and overtakes pending MFMAs in the hardware), then reads the clock.
 #ifdef S5_PHASE_PROF
 __device__ long long g_phase_prof[2048 * 8];
-#define PHASE_DECL long long prof_last = 0, prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); prof_last = t_; }
-#define PHASE_MARK(i, reg) do { long long t_; int d_; asm volatile("v_mov_b32 %1, %2\n\ts_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=v"(d_) : "v"(reg) : "memory"); prof_acc[i] += t_ - prof_last; prof_last = t_; } while (0)
-#define PHASE_DUMP do { if (threadIdx.x == 0 && blockIdx.x < 2048) for (int i_ = 0; i_ < 8; ++i_) g_phase_prof[blockIdx.x * 8 + i_] = prof_acc[i_]; } while (0)
+// all state in SGPRs (the kernels are at their register cap: per-lane accumulators would spill and the reloads would queue
+// behind the prefetch loads); 32-bit deltas are enough for one launch
+#define PHASE_DECL unsigned prof_last, prof_a0 = 0, prof_a1 = 0, prof_a2 = 0, prof_a3 = 0, prof_a4 = 0, prof_a5 = 0, prof_a6 = 0, prof_a7 = 0; \
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); prof_last = __builtin_amdgcn_readfirstlane((unsigned)t_); }
+#define PHASE_MARK(i, reg) do { unsigned long long t_; asm volatile("v_cmp_eq_u32 vcc, %1, %1\n\ts_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(reg) : "memory", "vcc"); \
+    const unsigned tl_ = __builtin_amdgcn_readfirstlane((unsigned)t_); prof_a##i = __builtin_amdgcn_readfirstlane(prof_a##i + (tl_ - prof_last)); prof_last = tl_; } while (0)
+#define PHASE_DUMP do { if (threadIdx.x == 0 && blockIdx.x < 2048) { long long *o_ = g_phase_prof + blockIdx.x * 8; o_[0] = prof_a0; o_[1] = prof_a1; o_[2] = prof_a2; o_[3] = prof_a3; \
+    o_[4] = prof_a4; o_[5] = prof_a5; o_[6] = prof_a6; o_[7] = prof_a7; } } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(i, reg)
