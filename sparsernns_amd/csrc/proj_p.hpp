@@ -184,13 +184,16 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int o = 32 * sub + 8 * g + 4 * h;
-                    if (o < nvalid) {
+                    // only the stores are guarded: with the arithmetic inside the branch the four groups of a lane run one
+                    // after the other, each a short dependent chain, and three waves per SIMD do not hide that
+                    const bool live = o < nvalid;
+                    {
                         v4i q;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int32_t bu = sat(asr(acc[4 * g + e], rs), bits);
                             q[e] = asr(wshl(bu, lsh), rsh);
-                            if (TRACE) {
+                            if (TRACE && live) {
                                 if (!cc && a.tr_bu_re) a.tr_bu_re[(n0 + o + e) * PC + p] = bu;
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
                             // recurrence kernel's helper wave forms K.  h = 0 / 1 lanes hold the two blocks of a pair, so one
                             // wave store fills 512 contiguous bytes
                             const int32_t o0 = __builtin_amdgcn_ds_swizzle(q[0], 0x401f), o2 = __builtin_amdgcn_ds_swizzle(q[2], 0x401f);
-                            *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, (t0 + o) >> 2, p, cc, a.TB, PC)) =
-                                pack4_i16(o0, o2, q[1], q[3]);
+                            const v2i item = pack4_i16(o0, o2, q[1], q[3]);
+                            if (live) *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, (t0 + o) >> 2, p, cc, a.TB, PC)) = item;
                         } else if (SM == 2) {
                             // K = (Bu << 16) + k.  Pair-native items: lane A = [Kim0 Kim2 Kre1 Kre3], lane B = [Kre0 Kre2
                             // Kim1 Kim3]: steps 0 and 2 come from the OTHER component's lane (r ^ 16, ds_swizzle), steps 1
@@ -214,11 +217,12 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
                             item[1] = __builtin_amdgcn_ds_swizzle(k2, 0x401f);
                             item[2] = wadd(wshl(q[1], 16), kc);
                             item[3] = wadd(wshl(q[3], 16), kc);
-                            *reinterpret_cast<v4i *>(a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC) + 4 * cc) = item;
-                        } else if (SM == 1)
-                            *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
-                                pack4_i16(q[0], q[1], q[2], q[3]);
-                        else
+                            if (live) *reinterpret_cast<v4i *>(a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC) + 4 * cc) = item;
+                        } else if (SM == 1) {
+                            if (live)
+                                *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
+                                    pack4_i16(q[0], q[1], q[2], q[3]);
+                        } else if (live)
                             *reinterpret_cast<v4i *>(a.bq + native_word(b0, t0 + o, p, cc, a.TB, PC)) = q;
                     }
                 }
