@@ -9,7 +9,8 @@
  *     (e.g. torch.Tensor.data_ptr()), `stream` is a hipStream_t passed as void*;
  *   - the caller owns every device buffer; nothing here allocates device memory
  *     (sizes come from the *_bytes query functions);
- *   - every call is asynchronous on `stream` and re-entrant (no global mutable state);
+ *   - every call is asynchronous on `stream` and re-entrant (no global mutable state; the S5FXP_* environment switches
+ *     listed under "Environment" below are read once, by s5fxp_model_create, into the handle it returns);
  *   - return value: S5FXP_OK or a negative error code; no exceptions cross the ABI;
  *   - errors that the reference raises from data-dependent values (a negative shift in
  *     fxp_mul's "compute_best", fxparray.py:619-621) are reported through a device status
@@ -197,8 +198,13 @@ size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L);
 
 /* Number of int32 words in the device status buffer, and its layout:
  *   [0] error bits (S5FXP_ST_*), [1] decoder output exponent,
- *   [8 + 8*l + 0..4] layer l: exponents chosen by the 4 BatchNorm ops and the residual add. */
+ *   [2] which kernels this forward ran: S5FXP_PATH_GENERIC (one-lane / VALU kernels, any int32 operands) or
+ *       S5FXP_PATH_FUSED (the int8-MFMA tile kernels + the quad / pair recurrence kernels),
+ *   [8 + 8*l + 0..4] layer l: exponents chosen by the 4 BatchNorm ops and the residual add,
+ *   [8 + 8*l + 5]    layer l: the recurrence kernel that was enqueued first, coded as s5fxp_model_recurrence_kernel
+ *                    (5 = the exact 32-bit quad chain of a S5FXP_FWD_EXACT forward). */
 #define S5FXP_STATUS_WORDS 128
+enum { S5FXP_PATH_GENERIC = 1, S5FXP_PATH_FUSED = 2 };
 enum {
     S5FXP_ST_NEGSHIFT = 1,   /* a data-dependent shift came out negative: the reference raises ValueError */
     S5FXP_ST_NEGEXP = 2,     /* a compute_best exponent came out negative (1 << exp fails in the reference) */
@@ -257,11 +263,19 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
                         void *workspace, size_t workspace_bytes, int32_t *status, const s5fxp_layer_trace *traces,
                         const s5fxp_forward_opts *opts, void *stream);
 
+/* Environment (experiments and tests only; read ONCE by s5fxp_model_create and stored in the handle, never by a forward):
+ *   S5FXP_NO_PAIR, S5FXP_PAIR_GLOBAL, S5FXP_PAIRL_BLOCKS=16   recurrence kernel choice (see s5fxp_model_recurrence_kernel)
+ *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT                             unpacked gate epilogues / four-reduction BatchNorm exponents
+ *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
+ *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward
+ * Results do not depend on any of them. */
+
 /* Static facts about a created model (for INTEGRATION / debugging). */
 int s5fxp_model_out_exp(const s5fxp_model *m);
 int s5fxp_model_out_bits(const s5fxp_model *m);
 /* 1 if the int8-MFMA kernels were packed for this model (NDNS shapes, <= 8-bit weights, <= 16-bit
- * activations); the forward uses them whenever L % 4 == 0 and falls back to the generic kernels otherwise. */
+ * activations); every forward of such a model runs them, whatever B and L (a sequence's last 4-step block may be
+ * partial: L = 3751, the N-DNS clips' native length, or single frames of a stream).  status[2] reports it per forward. */
 int s5fxp_model_is_fast(const s5fxp_model *m);
 /* Which recurrence kernel an optimistic forward (S5FXP_FWD_DEFER_REDO) runs for `layer`:
  * 0 one lane per state (generic), 1 quad kernel with int32 streams, 2 quad kernel with int16 streams,

@@ -25,6 +25,7 @@ S5FXP_OK, S5FXP_EBADARG, S5FXP_ENEGSHIFT, S5FXP_EUNSUPPORTED, S5FXP_EHIP, S5FXP_
 ST_NEGSHIFT, ST_NEGEXP, ST_WIDE_STATE, ST_WIDE_INPUT, ST_REDO = 1, 2, 4, 8, 16
 FWD_DEFER_REDO, FWD_EXACT, FWD_NO_PAIR = 1, 2, 4
 STATUS_WORDS = 128
+PATH_GENERIC, PATH_FUSED = 1, 2   # status[2]
 MODEL_DEFAULT, MODEL_FORCE_DENSE, MODEL_FORCE_CSR, MODEL_FORCE_GENERIC = 0, 1, 2, 4
 
 

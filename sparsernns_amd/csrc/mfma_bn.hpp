@@ -17,12 +17,21 @@
 
 namespace s5 {
 
-// one launch instead of two memsets at the head of a forward: the status words and the per-layer device state
-__global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb)
+// one launch instead of two memsets at the head of a forward: the status words and the per-layer device state.  What the
+// host knows before the forward goes into the status words here: [2] the path, [8 + 8l + 5] layer l's recurrence kernel.
+struct StatusInit {
+    int32_t path;
+    int32_t rk[15]; // 8 + 8 * n_layers <= S5FXP_STATUS_WORDS
+};
+__global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb, StatusInit si, int n_layers)
 {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) {
-        if (i < na) a[i] = 0;
-        else b[i - na] = 0;
+        if (i < na) {
+            int32_t v = 0;
+            if (i == 2) v = si.path;
+            else if (i >= 8 && (i & 7) == 5 && (i - 8) / 8 < n_layers) v = si.rk[(i - 8) / 8];
+            a[i] = v;
+        } else b[i - na] = 0;
     }
 }
 

@@ -256,7 +256,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
             if (ROUNDS * NTHR == ITEMS || q < ITEMS) {
                 const int grp = q / P, p = q % P;
                 int o = 4 * grp;
-                if (o >= nvalid) o = nvalid - 4; // partial tile: re-read the last block (results unused)
+                if (o >= nvalid) o = (nvalid - 1) & ~3; // partial tile: re-read the last block (results unused)
+                // steps of the sequence's last block beyond its length (L % 4 != 0): the recurrence ran on through them
+                // from whatever the stream holds there; they must not reach the range check
+                const int nlive = nvalid - o; // >= 1; >= 4 everywhere but in that block
                 int32_t w[4];
                 if (WIDE) {
                     const int32_t *src = a.xs + native_word(b0, t0 + o, p, 0, a.TB, P);
@@ -300,6 +303,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                     w[2] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x05040100u);
                     w[3] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x07060302u);
                     }
+                    if (nlive < 4) { // tile-uniform except in a sequence's last tile
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) w[j] = j < nlive ? w[j] : 0;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         pmax = __builtin_elementwise_max(pmax, __builtin_bit_cast(v2i16, w[j]));
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
                 const v4i cre = *reinterpret_cast<const v4i *>(src), cim = *reinterpret_cast<const v4i *>(src + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int32_t xr = cre[j], xi = cim[j];
+                    const int32_t xr = j < nlive ? cre[j] : 0, xi = j < nlive ? cim[j] : 0;
                     const uint32_t ur = (uint32_t)(xr + a.xmax), ui = (uint32_t)(xi + a.xmax);
                     xrange = xrange > ur ? xrange : ur;
                     xrange = xrange > ui ? xrange : ui;

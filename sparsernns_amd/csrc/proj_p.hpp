@@ -53,7 +53,7 @@ __device__ __forceinline__ void planes8_from_i32(const int32_t (&v)[8], v2i &hi,
 // Tiles of the per-layer kernels are 64 steps of ONE sequence inside a step range [t_lo, t_lo + t_len) (the
 // whole sequence, or one chunk of the bproj | scan | cgate pipeline): tile -> (sequence, first step, valid steps)
 struct StepRange {
-    int32_t t_lo, t_len; // multiples of 4 (t_lo: of 64)
+    int32_t t_lo, t_len; // t_lo: a multiple of 64; t_len: any length >= 1 (a sequence's last 4-step block may be partial)
 };
 template <int FT = 64>
 __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64_t &b, int &t, int &nvalid)
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
                         for (int e = 0; e < 4; ++e) {
                             const int32_t bu = sat(asr(acc[4 * g + e], rs), bits);
                             q[e] = asr(wshl(bu, lsh), rsh);
-                            if (TRACE && live) {
+                            if (TRACE && o + e < nvalid) {
                                 if (!cc && a.tr_bu_re) a.tr_bu_re[(n0 + o + e) * PC + p] = bu;
                                 if (cc && a.tr_bu_im) a.tr_bu_im[(n0 + o + e) * PC + p] = bu;
                             }

@@ -304,11 +304,42 @@ struct LayerDev {
 
 struct FastModel; // int8-MFMA path (s5fxp_fast.hpp); nullptr when the model is not eligible
 
+// Experiment / test switches.  They are read from the environment ONCE, in s5fxp_model_create, and live in the handle:
+// a forward never consults the environment, so s5fxp_model_recurrence_kernel always reports what s5fxp_model_forward
+// runs and two handles with different switches can be used side by side (include/s5fxp.h, "Environment").
+struct ModelCfg {
+    bool debug_sync = false;  // S5FXP_DEBUG_SYNC: synchronise + check after every stage of the fused forward
+    bool no_bn_ext = false;   // S5FXP_NO_BN_EXT: four full BatchNorm reductions instead of the per-channel extremes
+    bool no_pair = false;     // S5FXP_NO_PAIR: never the pair recurrence kernel
+    bool pair_global = false; // S5FXP_PAIR_GLOBAL: pair kernel fed from an int32 K stream in global memory (no helper wave)
+    bool no_pk16 = false;     // S5FXP_NO_PK16: unpacked epilogues in the gate kernel
+    int pairl_blocks = 32;    // S5FXP_PAIRL_BLOCKS=16: 16 time blocks per LDS buffer of the LDS-fed pair kernel
+    int64_t cap_enc = 512, cap_dec = 512, cap_cgate = 512, cap_bproj = 1024, cap_resid = 512; // S5FXP_WGS_*: workgroups per launch
+    static ModelCfg from_env()
+    {
+        ModelCfg c;
+        auto on = [](const char *n) { return std::getenv(n) != nullptr; };
+        auto cap = [](const char *n, int64_t dflt) {
+            const char *e = std::getenv(n);
+            const int v = e ? std::atoi(e) : 0;
+            return (int64_t)(v > 0 ? v : dflt);
+        };
+        c.debug_sync = on("S5FXP_DEBUG_SYNC"); c.no_bn_ext = on("S5FXP_NO_BN_EXT"); c.no_pair = on("S5FXP_NO_PAIR");
+        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16");
+        { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); c.pairl_blocks = e && std::atoi(e) == 16 ? 16 : 32; }
+        c.cap_enc = cap("S5FXP_WGS_ENC", c.cap_enc); c.cap_dec = cap("S5FXP_WGS_DEC", c.cap_dec);
+        c.cap_cgate = cap("S5FXP_WGS_CGATE", c.cap_cgate); c.cap_bproj = cap("S5FXP_WGS_BPROJ", c.cap_bproj);
+        c.cap_resid = cap("S5FXP_WGS_RESID", c.cap_resid);
+        return c;
+    }
+};
+
 struct s5fxp_model {
     int n_layers = 0, d_in = 0, H = 0, P = 0, d_out = 0;
     DenseDev enc, dec;
     std::vector<LayerDev> layers;
     int flags = 0;
+    ModelCfg cfg;
     FastModel *fast = nullptr;
 };
 
@@ -492,6 +523,7 @@ extern "C" int s5fxp_model_create(const s5fxp_model_desc *desc, void *dev_blob, 
     m->P = desc->n_layers ? desc->layers[0].ssm.P : 0;
     m->d_out = desc->decoder.M;
     m->flags = flags;
+    m->cfg = ModelCfg::from_env();
     m->layers.resize(desc->n_layers);
     std::vector<char> host(need);
     Packer p;
@@ -536,11 +568,10 @@ extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
 {
     if (!m || layer < 0 || layer >= m->n_layers) return -1;
     const LayerDev &l = m->layers[layer];
-    const s5fxp_ssm_desc &s = l.sd;
     if (!m->fast) return l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
-    if (!l.quad_ok) return 1; // the MFMA path's recurrence is always a quad kernel (32-bit chain when not quad_ok)
-    const bool s16 = s.Bu_re_bits - (s.Bu_re_exp - s.x_re_exp) <= 16 && s.Bu_im_bits - (s.Bu_im_exp - s.x_im_exp) <= 16;
-    return s16 ? (l.pair_ok && !std::getenv("S5FXP_NO_PAIR") ? (std::getenv("S5FXP_PAIR_GLOBAL") ? 3 : 4) : 2) : 1;
+    // the fused path: the same decision forward_fast takes (and reports in status word [8 + 8*layer + 5])
+    const int code = select_rung(m, layer, S5FXP_FWD_DEFER_REDO, false).code;
+    return code == RK_EXACT ? 1 : code; // no fast rung applies: a quad kernel all the same, the 32-bit chain
 }
 
 namespace {
@@ -585,8 +616,9 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
 {
     if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
     if (workspace_bytes < s5fxp_workspace_bytes(m, B, L)) return S5FXP_EWORKSPACE;
-    if (m->fast && (L % 4) == 0 && (int64_t)B * L * m->d_in * 4 < 0xfffffff0ll)
-        return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
+    // the recurrence kernels address one (sequence, state group) run of a stream through a 32-bit buffer extent
+    if ((((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 >= 0xffffffffll) return S5FXP_EBADARG;
+    if (m->fast) return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
@@ -603,7 +635,13 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
     const int64_t NH = N * H;
     const unsigned tiles = (unsigned)((N + TN - 1) / TN);
     int rc;
-    if ((rc = hip_rc(hipMemsetAsync(status, 0, sizeof(int32_t) * S5FXP_STATUS_WORDS, st)))) return rc;
+    {
+        StatusInit si{};
+        si.path = S5FXP_PATH_GENERIC;
+        for (int li = 0; li < m->n_layers; ++li)
+            si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers);
+    }
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1), st)))) return rc;
 
     // ---- encoder + ReLU (fxpmodel.py:1263-1266)

@@ -211,21 +211,53 @@ inline unsigned mfma_grid(int64_t N)
     return (unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
 }
 
+// Which recurrence kernel a fused forward with these S5FXP_FWD_* flags runs for layer li.  Codes 1..4 as
+// s5fxp_model_recurrence_kernel (include/s5fxp.h); RK_EXACT = the exact 32-bit chain (k_scan_quad32_asm).  The one place
+// that decides: forward_fast launches by it, the status words report it, the query answers from it.
+enum { RK_LANE = 0, RK_QUAD32 = 1, RK_QUAD16 = 2, RK_PAIR = 3, RK_PAIRL = 4, RK_EXACT = 5 };
+struct Rung {
+    bool exact, defer, quad, s16, pair, pairl;
+    int code;
+};
+Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced)
+{
+    const LayerDev &l = m->layers[li];
+    const s5fxp_ssm_desc &s = l.sd;
+    Rung r{};
+    r.exact = (fwd_flags & S5FXP_FWD_EXACT) != 0;
+    r.defer = (fwd_flags & S5FXP_FWD_DEFER_REDO) && !r.exact;
+    r.quad = l.quad_ok && !r.exact;
+    const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
+    // optimistic forwards (the caller repeats with S5FXP_FWD_EXACT if the range check fires) keep both recurrence
+    // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
+    // B projection's output, of both sides of the recurrence and of the gate kernel's state input
+    r.s16 = r.defer && r.quad && !traced && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
+    // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
+    // per state, four instructions per step), fed either from an int16 Bu stream through LDS by a helper wave (default:
+    // the HBM bytes of the quad16 path) or from an int32 K stream in global memory (ModelCfg::pair_global)
+    r.pair = r.s16 && l.pair_ok && !m->cfg.no_pair && !(fwd_flags & S5FXP_FWD_NO_PAIR);
+    r.pairl = r.pair && !m->cfg.pair_global;
+    r.code = r.pairl ? RK_PAIRL : r.pair ? RK_PAIR : r.quad ? (r.s16 ? RK_QUAD16 : RK_QUAD32) : RK_EXACT;
+    return r;
+}
+
 int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, void *workspace,
                  int32_t *status, const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, hipStream_t st)
 {
     const FastModel &F = *m->fast;
+    const ModelCfg &cfg = m->cfg;
+    const int fwd_flags = opts ? opts->flags : 0;
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
     const int32_t *state_in = opts ? opts->state_in : nullptr;
     int32_t *state_out = opts ? opts->state_out : nullptr;
-    const bool exact = opts && (opts->flags & S5FXP_FWD_EXACT);
-    const bool defer = opts && (opts->flags & S5FXP_FWD_DEFER_REDO) && !exact;
+    const bool exact = (fwd_flags & S5FXP_FWD_EXACT) != 0;
+    const bool defer = (fwd_flags & S5FXP_FWD_DEFER_REDO) && !exact;
     const FastWs w = fast_ws(m, B, L);
-    // S5FXP_DEBUG_SYNC=1: synchronise and check for launch / execution errors after every stage (names the stage that failed);
-    // off by default -- a forward has no host synchronisation, and launch errors are collected once at the end
-    static const bool debug_sync = std::getenv("S5FXP_DEBUG_SYNC") != nullptr;
+    // ModelCfg::debug_sync: synchronise and check for launch / execution errors after every stage (names the stage that
+    // failed); off by default -- a forward has no host synchronisation, and launch errors are collected once at the end
+    const bool debug_sync = cfg.debug_sync;
     auto stage_ok = [&](const char *what, int layer) -> bool {
         if (!debug_sync) return true;
         hipError_t e = hipGetLastError();
@@ -244,13 +276,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const bool big = (H == 192);
     const unsigned grid = mfma_grid(N);
     int rc;
+    // the status words start from zero except what the host already knows: which path runs ([2]) and which recurrence
+    // kernel each layer gets ([8 + 8l + 5])
+    StatusInit si{};
+    si.path = S5FXP_PATH_FUSED;
+    for (int li = 0; li < m->n_layers; ++li) si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr).code;
     hipLaunchKernelGGL(k_clear2, dim3(8), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
-                       (int)(w.dyn_bytes / 4));
+                       (int)(w.dyn_bytes / 4), si, m->n_layers);
     // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
     // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
-    // S5FXP_NO_BN_EXT=1 (tests): take the four-reduction path even when the extremes method applies
-    static const bool no_bn_ext = std::getenv("S5FXP_NO_BN_EXT") != nullptr;
-    bool bn_ext = !no_bn_ext && m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
+    // ModelCfg::no_bn_ext (tests): take the four-reduction path even when the extremes method applies
+    bool bn_ext = !cfg.no_bn_ext && m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
     for (int li = 0; li < m->n_layers; ++li) {
         const s5fxp_norm_desc &n = m->layers[li].nd;
         auto ok = [](int bits, int e) { return bits <= 16 && e >= 0 && e <= 15; };
@@ -259,15 +295,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                  m->layers[li].res_bits <= 16;
     }
 
-    // workgroups per launch (persistent loops over tiles): tuned per kernel on MI355X (256 CUs), S5FXP_WGS_* override them
-    auto wgs_cap = [](const char *name, int dflt) {
-        const char *e = std::getenv(name);
-        const int v = e ? std::atoi(e) : 0;
-        return (int64_t)(v > 0 ? v : dflt);
-    };
-    static const int64_t cap_enc = wgs_cap("S5FXP_WGS_ENC", 512), cap_dec = wgs_cap("S5FXP_WGS_DEC", 512),
-                         cap_cgate = wgs_cap("S5FXP_WGS_CGATE", 512), cap_bproj = wgs_cap("S5FXP_WGS_BPROJ", 1024),
-                         cap_resid = wgs_cap("S5FXP_WGS_RESID", 512);
+    // workgroups per launch (persistent loops over tiles): tuned per kernel on MI355X (256 CUs); ModelCfg (S5FXP_WGS_* at
+    // model creation) overrides them
+    const int64_t cap_enc = cfg.cap_enc, cap_dec = cfg.cap_dec, cap_cgate = cfg.cap_cgate, cap_bproj = cfg.cap_bproj,
+                  cap_resid = cfg.cap_resid;
     // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles
     const int64_t tiles64 = (N + 63) / 64;
     auto grid_for = [&](int64_t tiles, int64_t cap) {
@@ -379,19 +410,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
         // ---- B projection -> scan-native stream (+ u for the C projection)
         const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
-        const bool quad = l.quad_ok && !exact;
-        // optimistic forwards (the caller repeats with S5FXP_FWD_EXACT if the range check fires) keep both recurrence
-        // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
-        // B projection's output, of both sides of the recurrence and of the gate kernel's state input
-        const bool s16 = defer && quad && !tr && s.Bu_re_bits - sh_re <= 16 && s.Bu_im_bits - sh_im <= 16;
-        // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
-        // per state, four instructions per step; K stream int32 in, int16 states out).  S5FXP_NO_PAIR=1 (tests, profiling)
-        static const bool no_pair = std::getenv("S5FXP_NO_PAIR") != nullptr;
-        const bool pair = s16 && l.pair_ok && !no_pair && !(opts && (opts->flags & S5FXP_FWD_NO_PAIR));
-        // the pair kernel is fed either from an int16 Bu stream through LDS by a helper wave (default: the HBM bytes of the
-        // quad16 path) or from an int32 K stream in global memory (S5FXP_PAIR_GLOBAL=1)
-        static const bool pair_global = std::getenv("S5FXP_PAIR_GLOBAL") != nullptr;
-        const bool pairl = pair && !pair_global;
+        const Rung rung = select_rung(m, li, fwd_flags, tr != nullptr);
+        const bool quad = rung.quad, s16 = rung.s16, pair = rung.pair, pairl = rung.pairl;
         {
             BprojM2Args a{};
             a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
@@ -451,14 +471,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
             // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
-            static const int blocks = [] { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); return e && std::atoi(e) == 16 ? 16 : 32; }();
+            const int blocks = cfg.pairl_blocks;
             const dim3 sgrid((unsigned)((int64_t)B * (P / 32)));
             auto launch_pairl = [&](auto kernel, int smem_bytes) {
-                static bool attr_set = false; // > 64 KB of dynamic LDS needs the attribute once per kernel
-                if (smem_bytes > 65536 && !attr_set) {
+                if (smem_bytes > 65536) // > 64 KB of dynamic LDS needs the attribute (idempotent, a host-side table update)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-                    attr_set = true;
-                }
                 if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, ev0, ev1, 0, q);
                 else hipLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, q);
             };
@@ -525,8 +542,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
             const bool direct = s16 && fl.sigdir_bits > 0;
             // packed int16 epilogues (mfma_fused.hpp PK16): every width they touch is 16, no out2 input conversion
-            static const bool no_pk16 = std::getenv("S5FXP_NO_PK16") != nullptr;
-            const bool pk16 = direct && !tr && !no_pk16 && fl.bias16 && s.y_bits == 16 && ga.out_bits == 16 && l.res_bits == 16 &&
+            const bool pk16 = direct && !tr && !cfg.no_pk16 && fl.bias16 && s.y_bits == 16 && ga.out_bits == 16 && l.res_bits == 16 &&
                               l.l_bits == 16 && !ga.conv && l.l_exp - s.y_exp <= 14;
             const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
                                 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;

@@ -79,6 +79,85 @@ def test_two_d_input_and_ragged_tail():
         assert np.array_equal(y.numpy(), ref)
 
 
+def _ran_fused(eng, n_layers, rung=None, lane=0):
+    """What the forward that just ran on `lane` reports in its status words: the fused MFMA path, and (optionally) the
+    recurrence kernel of every layer (include/s5fxp.h: status[2], status[8 + 8l + 5])."""
+    from sparsernns_amd import _lib
+    st = eng.lane_status(lane).cpu().numpy()
+    assert _lib.lib.s5fxp_model_is_fast(eng._h) == 1
+    assert st[2] == _lib.PATH_FUSED, st[:8]
+    if rung is not None:
+        assert [int(st[8 + 8 * i + 5]) for i in range(n_layers)] == [rung] * n_layers, st[8:8 + 8 * n_layers]
+    return st
+
+
+@pytest.mark.parametrize("B", [1, 32])
+@pytest.mark.parametrize("L", [3751, 4097, 7, 1])
+def test_fused_path_at_any_sequence_length(B, L):
+    """the fused kernels must serve every sequence length -- N-DNS clips are 3751 frames
+    (sparseRNNs/dataloaders/dataloading.py:132-134: 3 mod 4), streams come a frame at a time.  The status words must say
+    that the MFMA tile kernels and the LDS-fed pair recurrence (code 4) ran, and the output must be the oracle's."""
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5, calib_L=1024, state_headroom_bits=1))   # bench.py's configs[1] model
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    fx = _input(qc, dims, B, L, seed=40 + L % 7)
+    ref, rb, re_, _ = cm.forward(fx.data, fx.bits, fx.exp)
+    y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))
+    assert (y.bits, y.exp) == (rb, re_)
+    assert np.array_equal(y.numpy(), ref)
+    st = _ran_fused(eng, dims["n_layers"], rung=4)
+    assert not (st[0] & _lib.ST_REDO) and eng.level == 0   # served by the top rung, no step down
+    # the self-contained form (gated exact kernels enqueued, int32 streams) and the traced form take the same tails
+    y2, tr = eng.forward(FxpArray(fx.data, fx.bits, fx.exp), traces=True, check_status=False)
+    assert np.array_equal(y2.numpy(), ref)
+    _ran_fused(eng, dims["n_layers"], rung=1)
+    if B == 1:
+        _, _, _, rtr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+        for i in range(dims["n_layers"]):
+            for k, ck in TRACE_MAP.items():
+                assert np.array_equal(tr[i][k].cpu().numpy(), rtr[i][ck]), f"layer {i} {k}"
+
+
+def test_ragged_tail_does_not_leak_into_the_range_check():
+    """The steps of a sequence's last 4-step block beyond L are computed by the recurrence too (the B projection fills them
+    with the last frame's Bu).  A sequence that ends on a burst keeps growing through those steps: the states there leave
+    every fast kernel's range while the L real ones do not.  They must not raise ST_REDO (a needless step down the
+    ladder), whichever rung runs, and the output must be the oracle's."""
+    import torch
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=0.5, calib_L=1024, state_headroom_bits=1))   # bench.py's configs[1] model
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    B, L = 3, 61                                               # 61 = 1 mod 4: three computed-but-unreal steps per sequence
+    xf = synth.make_input(B, L, dims["d_in"], seed=8)
+    xf[:, -1, :] *= 400.0                                      # the burst: saturates Bu in the last frame
+    fx = O.from_fp(xf, qc["encoder"]["inp_bits"], qc["encoder"]["inp_exp"], True, O.FLOOR)
+    ref, _, _, rtr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+    tops = [max(int(np.abs(t["xs_re"]).max()), int(np.abs(t["xs_im"]).max())) for t in rtr]
+    bounds = [_lib.lib.s5fxp_model_recurrence_xmax(eng._h, i) for i in range(dims["n_layers"])]
+    assert all(t <= b for t, b in zip(tops, bounds)), (tops, bounds)   # the real states fit the top rung
+    # what the kernel computes for the three extra steps of layer 0 = the oracle on the sequence with its last frame
+    # repeated (same extremes, hence the same exponents, in layer 0): those states are beyond every 16-bit bound
+    xpad = np.concatenate([fx.data, np.repeat(fx.data[:, -1:, :], 3, axis=1)], axis=1)
+    _, _, _, ptr = cm.forward(xpad, fx.bits, fx.exp, trace=True)
+    assert max(int(np.abs(ptr[0]["xs_re"][:, L:]).max()), int(np.abs(ptr[0]["xs_im"][:, L:]).max())) > 32767
+    x = torch.from_numpy(fx.data).cuda()
+    for flags, rung in ((_lib.FWD_DEFER_REDO, 4), (_lib.FWD_DEFER_REDO | _lib.FWD_NO_PAIR, 2), (0, 1), (_lib.FWD_EXACT, 5)):
+        y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+        eng.enqueue(x, fx.bits, fx.exp, y, B, L, flags=flags)
+        st = _ran_fused(eng, dims["n_layers"], rung=rung)
+        assert not (st[0] & (_lib.ST_REDO | _lib.ST_WIDE_STATE)), (flags, st[:8])
+        assert np.array_equal(y.cpu().numpy(), ref), flags
+
+
 def test_eager_matches_fused_and_names_intermediates():
     from sparsernns_amd.fxparray import FxpArray
     from sparsernns_amd.fxpmodel import build_regression_model
@@ -807,7 +886,8 @@ def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
     B = 2
     sess = eng.stream(B)
     ref_state = np.zeros((dims["n_layers"], 2, B, dims["P"]), dtype=np.int32)
-    lens = (64, 128, 36, 4, 200) if engine_flags == 0 else (64, 37, 5)   # the MFMA path needs L % 4 == 0
+    # both paths take any chunk length; the fused one down to single frames (real-time use)
+    lens = (64, 128, 36, 4, 200, 1, 3, 2, 37, 1) if engine_flags == 0 else (64, 37, 5)
     for i, L in enumerate(lens):
         fx = _input(qc, dims, B, L, seed=300 + i, scale=6.0 if i == 2 else 1.0)
         ref, rb, re_, _ = cm.forward(fx.data, fx.bits, fx.exp, state=ref_state)   # updates ref_state in place
@@ -815,6 +895,8 @@ def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
         assert (y.bits, y.exp) == (rb, re_)
         assert np.array_equal(y.numpy(), ref), f"chunk {i} (L={L})"
         assert np.array_equal(sess.state.cpu().numpy(), ref_state), f"carry after chunk {i}"
+        if engine_flags == 0:
+            _ran_fused(eng, dims["n_layers"])
     assert sess.frames == sum(lens) and np.abs(ref_state).max() > 0
     # zero carry == the stateless forward
     fx = _input(qc, dims, B, 64, seed=9)
