@@ -102,7 +102,10 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=32, help="sequences per pass of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
-    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (streams); 1 = one forward at a time")
+    ap.add_argument("--inflight", type=int, default=3, help="launch sets in flight (streams); 1 = one at a time")
+    ap.add_argument("--groups", type=int, default=4,
+                    help="reference batches per launch set (s5fxp_forward_opts::groups): G independent batches of --batch sequences, each "
+                         "its own compute_best batch, enqueued as one set of kernel launches; a step is still ONE batch")
     ap.add_argument("--no-scan-sweep", action="store_true", help="skip the extra recurrence-kernel measurement at 4x batch")
     ap.add_argument("--self-contained", action="store_true",
                     help="enqueue the gated exact re-run kernels with every forward (no status check needed)")
@@ -182,16 +185,18 @@ def main() -> None:
     # recurrence of one batch (a latency chain on B*P/16 waves) overlaps the projections of the others.  Every lane
     # has its own resident input and output; a step = one forward over one batch, as before.
     depth = 1 if (allreduce or args.self_contained) else max(1, args.inflight)
+    # G reference batches per launch set (one exponent group each; mode A and config 3's one global batch stay single)
+    G = 1 if (allreduce or sharded) else max(1, min(args.groups, args.steps))
     from sparsernns_amd.engine import InflightRunner
     fxs, ys = [], []
     for lane in range(depth):
         if sharded:  # this rank's slice of the one global batch of lane `lane`
             x = np.concatenate([synth.make_input(1, L, dims["d_in"], seed=100000 * lane + lo + i, scale=in_scale) for i in range(B)])
-        else:
-            x = synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane, scale=in_scale)  # every rank / lane its own batch
+        else:  # every rank / lane / group its own batch
+            x = np.concatenate([synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane + 4096 * g, scale=in_scale) for g in range(G)])
         fxs.append(fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
                                round_mode=RoundingMode.FLOOR))
-        ys.append(torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device=dev))
+        ys.append(torch.empty((G * B, L, dims["d_out"]), dtype=torch.int32, device=dev))
     fx, y = fxs[0], ys[0]
     n_ev = 2 * dims["n_layers"]
     nl = dims["n_layers"]
@@ -201,8 +206,11 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def n_sets(steps, g):
+        return (steps + g - 1) // g
+
     def make_events(steps):
-        # one layer's recurrence launch per step carries a pair of HIP events (rotating over the layers): the library
+        # one layer's recurrence launch per launch set carries a pair of HIP events (rotating over the layers): the library
         # attaches them to the dispatch (hipExtLaunchKernelGGL start/stop events), so elapsed_time() is that launch's
         # own duration -- the quantity rocprofv3's kernel trace reports -- and nothing extra is enqueued
         events = [[None] * n_ev for _ in range(steps)]
@@ -218,21 +226,26 @@ def main() -> None:
 
     exact_mode = False
 
-    def run(steps, d, events=None):
-        """`steps` forwards with d batches in flight.  d > 1: optimistic mode (the gated exact re-run launches are
-        dropped); the status words of every lane are checked afterwards and must not carry ST_REDO."""
+    def run(steps, d, events=None, g=None):
+        """`steps` forwards (= batches) as launch sets of g batches each (the last set takes what is left), d sets in flight.
+        d > 1: optimistic mode (the gated exact re-run launches are dropped); the status words of every lane are checked
+        afterwards and must not carry ST_REDO."""
+        g = G if g is None else g
+        sets = n_sets(steps, g)
         if d == 1:
             flags = 0 if (allreduce or args.self_contained) else type(eng).LEVEL_FLAGS[eng.level]
-            for k in range(steps):
+            for k in range(sets):
+                gk = min(g, steps - k * g)
                 eng.enqueue(fx.data, fx.bits, fx.exp, y, B, L, None, allreduce, flags=flags,
-                            scan_events=events[k] if events else None)
+                            scan_events=events[k] if events else None, groups=gk)
             return None
         runner = InflightRunner(eng, d) if run.runner is None else run.runner
         run.runner = runner
-        for k in range(steps):
+        for k in range(sets):
             lane = k % d
+            gk = min(g, steps - k * g)
             runner.submit(fxs[lane].data, fxs[lane].bits, fxs[lane].exp, ys[lane], B, L, check=False,
-                          scan_events=events[k] if events else None)
+                          scan_events=events[k] if events else None, groups=gk)
         return runner
 
     run.runner = None
@@ -257,7 +270,7 @@ def main() -> None:
     fallback_note = None
     # setup, not warmup: one forward per lane so that every lane's workspace and status words exist and every kernel
     # has been loaded before anything is timed, however small --warmup / --steps are
-    run(depth, depth)
+    run(depth * G, depth)
     torch.cuda.synchronize()
     probe = max(args.warmup, 1)
     run(probe, depth)
@@ -280,7 +293,7 @@ def main() -> None:
         raise SystemExit("the exact kernels reported ST_REDO: this cannot happen")
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    events = make_events(args.steps)
+    events = make_events(n_sets(args.steps, G))
     sync_all()
     t0 = time.perf_counter()
     run(args.steps, depth, events)
@@ -288,10 +301,10 @@ def main() -> None:
     dt = time.perf_counter() - t0
     st0 = check_all(depth)
 
-    # ---- the same K steps one at a time (no overlap between batches), for reference; not the headline
+    # ---- the same K steps one launch set at a time (no overlap between sets), for reference; not the headline
     single, ev1 = None, None
-    if depth > 1:
-        ev1 = make_events(args.steps)
+    if depth > 1 or G > 1:
+        ev1 = make_events(n_sets(args.steps, G))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         run(args.steps, 1, ev1)
@@ -299,14 +312,30 @@ def main() -> None:
         dt1 = time.perf_counter() - t1
         check_all(1)
         single = dict(ms_per_step=round(dt1 / args.steps * 1e3, 4), value=round(B * L * args.steps / dt1, 1),
-                      scan_avg_kernel_us=round(scan_avg(ev1) * 1e6, 2))
+                      scan_avg_kernel_us=round(scan_avg(ev1) * 1e6, 2), batches_per_launch=G)
+    # ---- ... and plain forwards of ONE batch, one at a time: the launch the recurrence kernel's roofline is quoted on
+    ev0 = None
+    if G > 1:
+        k0 = min(args.steps, 12 * nl)
+        ev0 = make_events(k0)
+        torch.cuda.synchronize()
+        run(k0, 1, ev0, g=1)
+        torch.cuda.synchronize()
+        check_all(1)
 
+    rank_values = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # every rank's own clock over the same K steps: the slowest one is the job's (contract); all of them are reported so
+        # that a scaling run can be read rank by rank against the N=1 line
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = dt
         if dist.get_backend() != "nccl":
             t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.tolist()]
+        dt = max(per_rank)
+        rank_values = dict(min=round(B * L * args.steps / max(per_rank), 1), max=round(B * L * args.steps / min(per_rank), 1),
+                           per_rank=[round(B * L * args.steps / v, 1) for v in per_rank])
     frames = B * L * world * args.steps
     value = frames / dt
     total_bl = B * L * world
@@ -316,9 +345,8 @@ def main() -> None:
     # flight: there its launches share the chip with other batches' projections and the bracket measures the
     # sharing, not the kernel -- that figure is reported beside it).
     scan_inflight_s = scan_avg(events)
-    scan_avg_s = scan_avg(ev1) if depth > 1 else scan_inflight_s
+    scan_avg_s = scan_avg(ev0) if ev0 is not None else (scan_avg(ev1) if ev1 is not None else scan_inflight_s)
     algo_bytes = B * L * dims["P"] * 16
-    achieved = algo_bytes / scan_avg_s / 1e9
     # optimistic forwards (everything but --self-contained / mode A) run the int16-stream variant of the kernel: the
     # algorithmic bytes stay SURVEY.md 8(d)'s 16*P per frame (the reference's int32 element type); what the kernel
     # actually moves is in `traffic` (PMC) and `stored_bytes_per_launch`
@@ -331,23 +359,34 @@ def main() -> None:
     traffic = pmc_traffic(B, L, dims["P"], scan_kernel)
     stored = scan_stored_bytes(scan_kernel, algo_bytes)
     moved = traffic if traffic is not None else stored
-    roofline = dict(bound="hbm", kernel=scan_kernel + " (the S5 recurrence)", achieved=round(achieved, 1),
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=traffic, avg_kernel_us=round(scan_avg_s * 1e6, 2),
-                    definition="achieved/frac: SURVEY.md 8(d) ALGORITHMIC bytes (16*P per frame: the reference's int32 "
-                               "Bu in + states out) / launch duration; moved_*: the bytes this kernel really moves "
-                               "(PMC traffic when measured on this workload, else its stream sizes) / the same duration",
-                    algorithmic_bytes_per_launch=algo_bytes, stored_bytes_per_launch=stored,
-                    moved_gbs=round(moved / scan_avg_s / 1e9, 1), moved_frac=round(moved / scan_avg_s / 1e9 / HBM_PEAK_GBS, 4),
-                    measured=("HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per step, " +
-                              ("in the one-at-a-time pass of the same K steps" if depth > 1 else "in the timed region")),
-                    avg_kernel_us_sharing_the_gpu=round(scan_inflight_s * 1e6, 2) if depth > 1 else None)
+    def roof(bytes_algo, bytes_moved, seconds):
+        """SURVEY.md 8(d): `frac` is quoted on the ALGORITHMIC bytes (16*P per frame, the reference's int32 element type);
+        `frac_moved` on what the kernel really moves.  The optimistic kernels keep int16 streams and move half of the
+        algorithmic bytes, so on a launch that fills the chip the algorithmic rate can exceed the HBM peak: a fraction
+        above one is not a bandwidth fraction of anything, and `frac` then falls back to the moved bytes (and says so)."""
+        fa, fm = bytes_algo / seconds / 1e9 / HBM_PEAK_GBS, bytes_moved / seconds / 1e9 / HBM_PEAK_GBS
+        on_moved = fa > 1.0
+        return dict(achieved=round((bytes_moved if on_moved else bytes_algo) / seconds / 1e9, 1), frac=round(fm if on_moved else fa, 4),
+                    frac_basis="moved bytes (the algorithmic rate would exceed the peak)" if on_moved else "algorithmic bytes (SURVEY.md 8d)",
+                    frac_algorithmic=round(fa, 4), frac_moved=round(fm, 4), avg_kernel_us=round(seconds * 1e6, 2),
+                    algorithmic_bytes_per_launch=bytes_algo, moved_bytes_per_launch=bytes_moved)
+
+    roofline = dict(bound="hbm", kernel=scan_kernel + " (the S5 recurrence)", peak=HBM_PEAK_GBS, unit="GB/s", traffic=traffic,
+                    **roof(algo_bytes, moved, scan_avg_s),
+                    stream_width="int32 arithmetic; " + ("int16 range-guarded streams (Bu in, states out): every stored state is checked against the "
+                                                         "kernel's exactness bound by its consumer" if stored < algo_bytes else "int32 streams"),
+                    moved_bytes_source="PMC (profiles/r0N_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "stream sizes",
+                    launch=f"one reference batch per launch (B={B}), one launch at a time",
+                    measured="HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per launch set",
+                    avg_kernel_us_in_the_timed_region=round(scan_inflight_s * 1e6, 2), batches_per_launch_in_the_timed_region=G)
+    if ev1 is not None and G > 1:  # the same kernel on the launches the headline is made of: G batches per launch, nothing else running
+        roofline["grouped_launch"] = dict(batches_per_launch=G, **roof(G * algo_bytes, G * stored, scan_avg(ev1)))
 
     # ---- the recurrence kernel with more chains than one reference batch gives it (not the headline workload): at
     # B=32 its launch is a latency chain on 128 waves, whatever the bandwidth; the same kernel at 4x the batch shows
     # what it moves when the chip is filled.  Single stream, a few steps, rank 0 of a 1-GPU run only.
     scan_big = None
-    if rank == 0 and world == 1 and optimistic and not args.no_scan_sweep:
+    if rank == 0 and world == 1 and optimistic and not args.no_scan_sweep and G == 1:
         Bb = 4 * B
         xb = synth.make_input(Bb, L, dims["d_in"], seed=77, scale=in_scale)
         fxb = fxp_from_fp(xb, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
@@ -360,11 +399,8 @@ def main() -> None:
             eng.enqueue(fxb.data, fxb.bits, fxb.exp, yb, Bb, L, flags=type(eng).LEVEL_FLAGS[eng.level], lane=9, scan_events=evb[k])
         torch.cuda.synchronize()
         if not (int(eng.check_status(9)[0]) & _lib.ST_REDO):
-            tb = scan_avg(evb)
             ab = Bb * L * dims["P"] * 16
-            scan_big = dict(batch=Bb, avg_kernel_us=round(tb * 1e6, 2), achieved=round(ab / tb / 1e9, 1), unit="GB/s",
-                            frac=round(ab / tb / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_launch=ab,
-                            stored_bytes_per_launch=ab // 2,
+            scan_big = dict(batch=Bb, unit="GB/s", **roof(ab, scan_stored_bytes(scan_kernel, ab), scan_avg(evb)),
                             note="same kernel, 4x the sequences in one launch (one exponent group); not the headline workload")
         del fxb, yb
 
@@ -426,10 +462,14 @@ def main() -> None:
                                   else f"B={B} x L={L} per GPU, ") +
                                  f"H={dims['H']}, P={dims['P']}, 3 layers, d_in=d_out=257",
                         batch_per_gpu=B, seq_len=L, exponent_mode="global (all-reduce MAX)" if allreduce else "per-shard",
-                        parallelism=f"batch-sharded x{world}", batches_in_flight=depth),
+                        parallelism=f"batch-sharded x{world}", batches_per_launch=G, launch_sets_in_flight=depth,
+                        batches_in_flight=depth * G,
+                        stream_width="int32 arithmetic and model input / output; int16 activations between kernels and int16 "
+                                     "range-guarded recurrence streams (a value outside the guarded range repeats the batch on "
+                                     "the exact int32 kernels)"),
             roofline=roofline, recurrence_kernel_at_4x_batch=scan_big, cpu_baseline=cpu, single_stream=single,
             mode=fallback_note or ("optimistic" if optimistic else "self-contained"), status_bits=int(st0),
-            output_gather_ms=gather_ms)
+            output_gather_ms=gather_ms, rank_values=rank_values)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

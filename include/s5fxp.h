@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S5FXP_VERSION 100
+#define S5FXP_VERSION 101
 
 enum {
     S5FXP_OK = 0,
@@ -255,6 +255,15 @@ typedef struct {
      * S5FXP_ST_REDO has left an unusable state_out, and its repeat needs the old state_in. */
     const int32_t *state_in;
     int32_t *state_out;
+    /* Grouped call (0 or 1: a plain forward).  groups = G > 1: x and y hold G * B sequences -- G independent reference
+     * batches of B sequences each, exactly what G calls with B sequences compute (every group is its own compute_best
+     * batch: own exponents, own status words, own carry), but enqueued as ONE set of kernel launches (gridDim.y = G on
+     * the fused path; a loop over the groups elsewhere).  Everything per-forward is G-fold and contiguous, group after
+     * group: workspace >= G * s5fxp_workspace_bytes(m, B, L) (that value is the group stride), status
+     * G * S5FXP_STATUS_WORDS words, state_in / state_out [G][n_layers][2][B][P], traces G * n_layers entries.  This is the
+     * reference's run_validation loop over batches (sparseRNNs/fxprun.py:53-88) taken several batches at a time: at the
+     * N-DNS batch of 32 sequences a launch costs about as much as a quarter of its work. */
+    int32_t groups;
 } s5fxp_forward_opts;
 
 /* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.

@@ -23,8 +23,10 @@ struct StatusInit {
     int32_t path;
     int32_t rk[15]; // 8 + 8 * n_layers <= S5FXP_STATUS_WORDS
 };
-__global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb, StatusInit si, int n_layers)
+__global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb, StatusInit si, int n_layers, GroupOff go)
 {
+    gshift(a, (int64_t)blockIdx.y * go.status);
+    gshift(b, (int64_t)blockIdx.y * go.ws);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < na + nb; i += gridDim.x * 256) {
         if (i < na) {
             int32_t v = 0;
@@ -220,26 +222,21 @@ struct ResidHead {
     int32_t *status_exps;
     int32_t enable; // 0: d->res was written by k_res_finalize
 };
-struct ResidTail {
-    BnArgs bn; // the next layer's (layer 0's for RESID=false)
-    LayerDyn *d_next;
-    int32_t *status_exps_next;
-    int32_t *ticket; // zeroed with the LayerDyn block
-    int32_t xe_static; // RESID=false: exponent of z
-    int32_t enable;    // the workgroup that finishes last derives the next layer's exponents (otherwise the consumer does)
-    int32_t reps;      // replicas of the extremes the atomics are spread over (1 or EXT_REPS)
-};
 
 constexpr int RESID_THREADS = 384;
 template <bool RESID>
 __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
                                                                   int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
                                                                   int64_t span, int res_bits, int skip_bits, ResidHead hd,
-                                                                  float *ext, ResidTail tl, int32_t *status)
+                                                                  float *ext, int ext_reps, int32_t *status, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift_nn(z, g * go.ws); gshift_nn(skip, g * go.ws); gshift_nn(out, g * go.ws); gshift(ext, g * go.ws);
+        gshift_nn(hd.d, g * go.ws); gshift(hd.skip_e.dyn, g * go.ws); gshift_nn(hd.status_exps, g * go.status); gshift_nn(status, g * go.status);
+    }
     __shared__ int32_t smin[RESID_THREADS * 8], smax[RESID_THREADS * 8];
     __shared__ AddCb sp;
-    __shared__ int last;
     const int G = H >> 3, R = RESID_THREADS / G;
     const int g = threadIdx.x % G, rl = threadIdx.x / G;
     // a round = four frames per thread.  The first round's loads are issued BEFORE the head below: its exponent arithmetic
@@ -341,18 +338,11 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
                 const int32_t t = smin[item];
                 v = is_max ? max(v, t) : min(v, t);
             }
-            const int rep = tl.reps > 1 ? (int)(blockIdx.x % tl.reps) : 0;
+            const int rep = ext_reps > 1 ? (int)(blockIdx.x % ext_reps) : 0;
             atomicMax(reinterpret_cast<uint32_t *>(ext) + rep * 2 * H + item,
                       __float_as_uint(is_max ? EXT_BIAS + (float)v : EXT_BIAS - (float)v));
         }
     }
-    if (!tl.enable) return;
-    // the extremes are agent-scope atomics; once this workgroup's are acknowledged it takes a ticket
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (last) (void)bn_finalize_mm_body(tl.bn, ext, H, tl.d_next, status, tl.status_exps_next, RESID ? p.eo : tl.xe_static, tl.reps);
 }
 
 

@@ -169,8 +169,14 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // packs, clamped packed sub / mad / add, SDWA half-word operands -- about a third fewer VALU instructions, same results
 template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false, bool PK16 = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
-__global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGateArgs a)
+__global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const CGateArgs a_k, GroupOff go)
 {
+    CGateArgs a = a_k; // (the LUT is indexed by thread below: that read stays on the kernel argument, so that this copy lives in registers)
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.u, g * go.ws); gshift(a.skip, g * go.ws); gshift(a.xs, g * go.ws); gshift(a.z, g * go.ws);
+        gshift(a.skip_e.dyn, g * go.ws); gshift(a.dynw, g * go.ws); gshift(a.run_if, g * go.ws); gshift(a.status, g * go.status);
+    }
     constexpr int P = 32 * KS, H = 32 * NT, FT = FTP, NW = (FT / 32) * NT, NTHR = 64 * NW; // one wave per (half, column tile)
     constexpr int KPS = 2 * P + 16, KPX = H + 16;
     constexpr int NU = 1, SUBSTEP = 0;   // units per wave
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(CGate
     if (PK16) // packed pairs (every value fits 16 bits: host-checked)
         for (int i = threadIdx.x; i < H / 2; i += NTHR)
             be[i] = (int32_t)(((uint32_t)a.bias_eff[2 * i] & 0xffffu) | ((uint32_t)a.bias_eff[2 * i + 1] << 16));
-    if (threadIdx.x < 8) lutp[threadIdx.x] = a.lut[threadIdx.x] | (a.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
+    if (threadIdx.x < 8) lutp[threadIdx.x] = a_k.lut[threadIdx.x] | (a_k.lut[threadIdx.x < 7 ? threadIdx.x + 1 : 7] << 16);
     if (DIRECT) {
         for (int i = threadIdx.x; i < (1 << a.sigdir_bits) / 2; i += NTHR)
             sigt[i] = reinterpret_cast<const int32_t *>(a.sigdir)[i];

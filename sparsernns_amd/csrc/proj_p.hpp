@@ -70,8 +70,13 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
 // K = (Bu << 16) + k in pair-native order, one 16-byte item per producer lane; 3: the LDS-fed pair kernel's int16 Bu
 // stream (pair16-native), one 8-byte item per producer lane
 template <int KS, int NT, bool TRACE, int SM = 0>
-__global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a)
+__global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.bn.dyn, g * go.ws); gshift(a.bn.xe.dyn, g * go.ws); gshift(a.x, g * go.ws); gshift(a.bq, g * go.ws); gshift(a.u, g * go.ws);
+        gshift(a.ext, g * go.ws); gshift(a.status, g * go.status); gshift(a.status_exps, g * go.status);
+    }
     constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
     constexpr int VPF = H / 8;             // 16-byte vectors per frame
     constexpr int NTHR = 64 * NT;          // one wave per column tile: 256 threads at dim 0.5, 512 at dim 1.0
@@ -301,12 +306,16 @@ __device__ __forceinline__ void mfma_nplanes(v16i &acc, const v4i (&w)[KSTEPS], 
 // plus the K-256 tail, converts, and writes byte planes [frame][304]; phase B: wave (half, column tile).
 // ext != nullptr: the per-channel extremes of the output (layer 0's BatchNorm operand, mfma_bn.hpp) are gathered
 // on the way -- a lane keeps (max, 65535 - min) of its 16 channels as packed u16 pairs (the output is >= 0 after
-// the ReLU) -- and with tl.enable the workgroup that finishes last derives layer 0's BatchNorm exponents.
+// the ReLU); the atomics are spread over ext_reps replicas (mfma_bn.hpp EXT_REPS).
 // LDS: [cs128 Np][bias_eff Np][X hi][X lo][ext hi H][ext lo H]
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float *ext, ResidTail tl)
+__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float *ext, int ext_reps, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.x, g * go.x); gshift(a.y, g * go.ws); gshift(a.status, g * go.status); gshift(ext, g * go.ws);
+    }
     constexpr int KS = 9, FT = 64, KP = 32 * KS + 16, NW = 6, H = 32 * NT;
     constexpr int NU = 2 * NT / NW, SUBSTEP = NW / NT;
     constexpr int RPW = (FT + NW - 1) / NW; // rows per wave
@@ -448,17 +457,10 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
     __syncthreads();
     if (threadIdx.x < a.M) { // max = ehi, min = 65535 - elo; as the positive floats of mfma_bn.hpp
         const int c = threadIdx.x;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(ext) + (tl.reps > 1 ? (int)(blockIdx.x % tl.reps) : 0) * 2 * a.M;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ext) + (ext_reps > 1 ? (int)(blockIdx.x % ext_reps) : 0) * 2 * a.M;
         atomicMax(dst + c, __float_as_uint(EXT_BIAS - (float)(65535 - (int)elo[c])));
         atomicMax(dst + a.M + c, __float_as_uint(EXT_BIAS + (float)ehi[c]));
     }
-    if (!tl.enable) return;
-    __shared__ int last;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(tl.ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (last) (void)bn_finalize_mm_body(tl.bn, ext, a.M, tl.d_next, a.status, tl.status_exps_next, tl.xe_static, tl.reps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,8 +470,12 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
 // LDS: [X hi][X lo]
 // ---------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a)
+__global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.x, g * go.ws); gshift(a.y, g * go.y); gshift(a.xe.dyn, g * go.ws); gshift(a.status, g * go.status);
+    }
     constexpr int H = 32 * KS, FT = 64, KP = H + 16, NW = 6, CT = 9, CPW = 3;
     constexpr int VPF = H / 8, NV = FT * VPF / 384;
     static_assert(FT * VPF % 384 == 0, "tile shape");

@@ -615,7 +615,28 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
                                    const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, void *stream)
 {
     if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
-    if (workspace_bytes < s5fxp_workspace_bytes(m, B, L)) return S5FXP_EWORKSPACE;
+    const int G = opts && opts->groups > 1 ? opts->groups : 1;
+    const size_t ws_one = s5fxp_workspace_bytes(m, B, L);
+    if (workspace_bytes < (size_t)G * ws_one) return S5FXP_EWORKSPACE;
+    if (G > 1) {
+        // Grouped call: G independent reference batches of B sequences each.  The fused kernels take them in ONE set of
+        // launches (gridDim.y = G) when nothing couples the groups on the host; otherwise one forward per group.
+        if (m->fast && !traces && !opts->allreduce && fast_bn_ext(m) &&
+            (((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 < 0xffffffffll)
+            return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream), G, ws_one);
+        const size_t plane = (size_t)m->n_layers * 2 * B * (m->P ? m->P : 1);
+        for (int g = 0; g < G; ++g) {
+            s5fxp_forward_opts o = *opts;
+            o.groups = 1;
+            if (o.state_in) o.state_in += g * plane;
+            if (o.state_out) o.state_out += g * plane;
+            const int rc = s5fxp_model_forward(m, x + (size_t)g * B * L * m->d_in, x_bits, x_exp, B, L, y + (size_t)g * B * L * m->d_out,
+                                               reinterpret_cast<char *>(workspace) + g * ws_one, ws_one, status + (size_t)g * S5FXP_STATUS_WORDS,
+                                               traces ? traces + (size_t)g * m->n_layers : nullptr, &o, stream);
+            if (rc) return rc;
+        }
+        return S5FXP_OK;
+    }
     // the recurrence kernels address one (sequence, state group) run of a stream through a 32-bit buffer extent
     if ((((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 >= 0xffffffffll) return S5FXP_EBADARG;
     if (m->fast) return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
@@ -640,7 +661,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         si.path = S5FXP_PATH_GENERIC;
         for (int li = 0; li < m->n_layers; ++li)
             si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
-        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers);
+        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
     }
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1), st)))) return rc;
 
@@ -729,7 +750,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             ScanQuadArgs q{};
             q.bq = I(w.bq); q.xs = I(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = sl.x0_re; q.x0_im = sl.x0_im;
-            hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+            hipLaunchKernelGGL(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q, GroupOff{});
             xmax = l.quad_xmax;
         } else {
             sl.run_if = nullptr;
@@ -755,7 +776,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
             if (state_out) // the raw states are still in the stream (either pass): carry out = state after frame L-1
                 hipLaunchKernelGGL(k_state_out, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const void *)I(w.xs), 0,
                                    (const int32_t *)nullptr, B, L, P, w.TB, state_out + (size_t)li * 2 * plane,
-                                   state_out + (size_t)li * 2 * plane + plane);
+                                   state_out + (size_t)li * 2 * plane + plane, GroupOff{});
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);

@@ -197,11 +197,11 @@ FastWs fast_ws(const s5fxp_model *m, int B, int L)
 }
 
 template <class K, class A>
-inline void launch_smem(K kernel, unsigned grid, size_t smem, hipStream_t st, const A &args, unsigned threads = 256)
+inline void launch_smem(K kernel, unsigned grid, size_t smem, hipStream_t st, const A &args, unsigned threads, int G, const GroupOff &go)
 {
     if (smem > 65536) // the dim_scale 1.0 tiles need more than the default dynamic-LDS limit
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), smem, st, args);
+    hipLaunchKernelGGL(kernel, dim3(grid, G), dim3(threads), smem, st, args, go);
 }
 
 // one workgroup = 4 waves x 32 frames; cap the grid at 4 workgroups per CU and let waves loop
@@ -241,8 +241,28 @@ Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced)
     return r;
 }
 
+// G > 1: a grouped launch (include/s5fxp.h s5fxp_forward_opts::groups): x, y, workspace, status and the carry arrays hold G
+// consecutive copies of what one forward uses; every kernel runs with gridDim.y = G (scan_quad.hpp GroupOff).  The caller
+// (s5fxp_model_forward) sends only hook-free, trace-free forwards here with G > 1.
+bool fast_bn_ext(const s5fxp_model *m)
+{
+    // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
+    // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
+    // ModelCfg::no_bn_ext (tests): take the four-reduction path even when the extremes method applies
+    bool bn_ext = !m->cfg.no_bn_ext && m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
+    for (int li = 0; li < m->n_layers; ++li) {
+        const s5fxp_norm_desc &n = m->layers[li].nd;
+        auto ok = [](int bits, int e) { return bits <= 16 && e >= 0 && e <= 15; };
+        bn_ext = bn_ext && ok(n.mean_bits, n.mean_exp) && ok(n.invsq_var_bits, n.invsq_var_exp) &&
+                 (!m->layers[li].scale || ok(n.scale_bits, n.scale_exp)) && (!m->layers[li].nbias || ok(n.bias_bits, n.bias_exp)) &&
+                 m->layers[li].res_bits <= 16;
+    }
+    return bn_ext;
+}
+
 int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y, void *workspace,
-                 int32_t *status, const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, hipStream_t st)
+                 int32_t *status, const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, hipStream_t st, int G = 1,
+                 size_t ws_stride = 0)
 {
     const FastModel &F = *m->fast;
     const ModelCfg &cfg = m->cfg;
@@ -255,6 +275,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     const bool exact = (fwd_flags & S5FXP_FWD_EXACT) != 0;
     const bool defer = (fwd_flags & S5FXP_FWD_DEFER_REDO) && !exact;
     const FastWs w = fast_ws(m, B, L);
+    GroupOff go{};
+    go.x = (int64_t)B * L * m->d_in * 4; go.y = (int64_t)B * L * m->d_out * 4; go.ws = (int64_t)(ws_stride ? ws_stride : w.total); go.status = 4 * S5FXP_STATUS_WORDS;
+    go.state_in = go.state_out = (int64_t)m->n_layers * 2 * B * (m->P ? m->P : 1) * 4;
     // ModelCfg::debug_sync: synchronise and check for launch / execution errors after every stage (names the stage that
     // failed); off by default -- a forward has no host synchronisation, and launch errors are collected once at the end
     const bool debug_sync = cfg.debug_sync;
@@ -281,19 +304,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     StatusInit si{};
     si.path = S5FXP_PATH_FUSED;
     for (int li = 0; li < m->n_layers; ++li) si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr).code;
-    hipLaunchKernelGGL(k_clear2, dim3(8), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
-                       (int)(w.dyn_bytes / 4), si, m->n_layers);
-    // BatchNorm exponents from per-channel extremes need every BN operand to be <= 16 bit with exponents in
-    // [0,15] (no int32 wrap -> every stage monotone, mfma_bn.hpp); otherwise the four full reductions run.
-    // ModelCfg::no_bn_ext (tests): take the four-reduction path even when the extremes method applies
-    bool bn_ext = !cfg.no_bn_ext && m->enc.out_bits <= 16 && m->enc.out_exp >= 0 && m->enc.out_exp <= 15;
-    for (int li = 0; li < m->n_layers; ++li) {
-        const s5fxp_norm_desc &n = m->layers[li].nd;
-        auto ok = [](int bits, int e) { return bits <= 16 && e >= 0 && e <= 15; };
-        bn_ext = bn_ext && ok(n.mean_bits, n.mean_exp) && ok(n.invsq_var_bits, n.invsq_var_exp) &&
-                 (!m->layers[li].scale || ok(n.scale_bits, n.scale_exp)) && (!m->layers[li].nbias || ok(n.bias_bits, n.bias_exp)) &&
-                 m->layers[li].res_bits <= 16;
-    }
+    hipLaunchKernelGGL(k_clear2, dim3(8, G), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
+                       (int)(w.dyn_bytes / 4), si, m->n_layers, go);
+    const bool bn_ext = fast_bn_ext(m);
 
     // workgroups per launch (persistent loops over tiles): tuned per kernel on MI355X (256 CUs); ModelCfg (S5FXP_WGS_* at
     // model creation) overrides them
@@ -309,13 +322,13 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     auto launch6g = [&](auto kernel, unsigned g6, size_t smem, const auto &args, unsigned threads = 384) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kernel, dim3(g6), dim3(threads), smem, st, args);
+        hipLaunchKernelGGL(kernel, dim3(g6, G), dim3(threads), smem, st, args, go);
     };
     auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid_dec, smem, args); };
-    auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, const ResidTail &tl) {
+    auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, int ext_reps) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kernel, dim3(grid_enc), dim3(384), smem, st, args, ext, tl);
+        hipLaunchKernelGGL(kernel, dim3(grid_enc, G), dim3(384), smem, st, args, ext, ext_reps, go);
     };
 
     // residual / extremes pass: a workgroup owns rm_span consecutive frames, a multiple of its 4 x R frame step
@@ -355,10 +368,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // the extremes of the output (layer 0's BatchNorm operand) are gathered on the way; single-rank mode also
         // lets the last workgroup derive layer 0's BatchNorm exponents (mfma_bn.hpp ResidTail)
         float *ext0 = bn_ext && m->n_layers > 0 ? reinterpret_cast<float *>(ws + w.ext) : nullptr;
-        ResidTail tl{};
-        tl.reps = (ext0 && !allreduce) ? EXT_REPS : 1; // the consumer (k_bproj_p's prologue) derives the exponents: tl.enable = 0
-        if (big) launch6x(k_enc_p<6>, smem, a, ext0, tl);
-        else launch6x(k_enc_p<3>, smem, a, ext0, tl);
+        const int ext_reps = (ext0 && !allreduce) ? EXT_REPS : 1; // the consumer (k_bproj_p's prologue) folds the replicas
+        if (big) launch6x(k_enc_p<6>, smem, a, ext0, ext_reps);
+        else launch6x(k_enc_p<3>, smem, a, ext0, ext_reps);
         if (!stage_ok("encoder", -1)) return S5FXP_EHIP;
     }
     // single-rank mode folds the two one-workgroup "finalize" kernels of every layer into the residual pass
@@ -433,22 +445,22 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 const unsigned bthr = big ? 512 : 256; // one wave per 32-column tile of [B_re | B_im]
                 const unsigned pgrid = (unsigned)((tl + per - 1) / per);
                 if (tr) {
-                    if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr, G, go);
+                    else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr, G, go);
                 } else if (pairl) {
                     a.w = fl.bproj_pair.w;
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 3>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, false, 3>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 3>, pgrid, smem, st, a, bthr, G, go);
+                    else launch_smem(k_bproj_p<3, 4, false, 3>, pgrid, smem, st, a, bthr, G, go);
                 } else if (pair) {
                     a.w = fl.bproj_pair.w;
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 2>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, false, 2>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 2>, pgrid, smem, st, a, bthr, G, go);
+                    else launch_smem(k_bproj_p<3, 4, false, 2>, pgrid, smem, st, a, bthr, G, go);
                 } else if (s16) {
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 1>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, false, 1>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, false, 1>, pgrid, smem, st, a, bthr, G, go);
+                    else launch_smem(k_bproj_p<3, 4, false, 1>, pgrid, smem, st, a, bthr, G, go);
                 } else {
-                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr);
-                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr);
+                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr, G, go);
+                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr, G, go);
                 }
             }
         }
@@ -462,8 +474,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         // what rocprofv3's kernel trace reports), not recorded around it
         hipEvent_t ev0 = scan_events ? (hipEvent_t)scan_events[2 * li] : nullptr, ev1 = scan_events ? (hipEvent_t)scan_events[2 * li + 1] : nullptr;
         auto launch_scan = [&](auto kernel, dim3 grid, dim3 block, auto args) {
-            if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, grid, block, 0, sst, ev0, ev1, 0, args);
-            else hipLaunchKernelGGL(kernel, grid, block, 0, sst, args);
+            grid.y = G;
+            if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, grid, block, 0, sst, ev0, ev1, 0, args, go);
+            else hipLaunchKernelGGL(kernel, grid, block, 0, sst, args, go);
         };
         if (pairl) {
             ScanPairLArgs q{};
@@ -472,12 +485,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
             // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
             const int blocks = cfg.pairl_blocks;
-            const dim3 sgrid((unsigned)((int64_t)B * (P / 32)));
+            const dim3 sgrid((unsigned)((int64_t)B * (P / 32)), G);
             auto launch_pairl = [&](auto kernel, int smem_bytes) {
                 if (smem_bytes > 65536) // > 64 KB of dynamic LDS needs the attribute (idempotent, a host-side table update)
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
-                if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, ev0, ev1, 0, q);
-                else hipLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, q);
+                if (ev0 && ev1) hipExtLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, ev0, ev1, 0, q, go);
+                else hipLaunchKernelGGL(kernel, sgrid, dim3(128), smem_bytes, sst, q, go);
             };
             if (blocks == 16) launch_pairl(k_scan_pairl_asm<16>, 3 * 16 * 1024);
             else launch_pairl(k_scan_pairl_asm<32>, 3 * 32 * 1024);
@@ -548,7 +561,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                                 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
-                if ((rc = hip_rc(hipMemsetAsync(&d->redo, 0xff, 4, st)))) return rc;
+                for (int g = 0; g < G; ++g)
+                    if ((rc = hip_rc(hipMemsetAsync(reinterpret_cast<char *>(&d->redo) + (size_t)g * go.ws, 0xff, 4, st)))) return rc;
             } else {
                 {
                     a.t_lo = 0; a.t_len = L;
@@ -588,7 +602,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     ScanQuadArgs q{};
                     q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
                     q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = &d->redo; q.x0_re = x0_re; q.x0_im = x0_im;
-                    hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), 0, st, q);
+                    hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16), G), dim3(64), 0, st, q, go);
                 }
                 // the exact gate kernel: four byte planes of the int32 states, no range assumption; its maxima go to
                 // slots 11..13, which the residual pass picks when `redo` is set
@@ -607,9 +621,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 }
             }
             if (state_out) // carry out: the state after frame L-1, from whichever kernel wrote the stream last
-                hipLaunchKernelGGL(k_state_out, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, (const void *)I32(w.xs),
+                hipLaunchKernelGGL(k_state_out, dim3((unsigned)((plane + 255) / 256), G), dim3(256), 0, st, (const void *)I32(w.xs),
                                    pair ? 2 : (s16 ? 1 : 0), defer ? (const int32_t *)nullptr : (const int32_t *)&d->redo, B, L, P,
-                                   w.TB, state_out + (size_t)li * 2 * plane, state_out + (size_t)li * 2 * plane + plane);
+                                   w.TB, state_out + (size_t)li * 2 * plane, state_out + (size_t)li * 2 * plane + plane, go);
             if (tr && (tr->xs_re || tr->xs_im))
                 hipLaunchKernelGGL(k_unpack_native, dim3(ew_grid(N * P)), dim3(256), 0, st, (const int32_t *)I32(w.xs),
                                    tr->xs_re, tr->xs_im, B, L, P, w.TB);
@@ -629,11 +643,10 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             ResidHead hd{};
             hd.d = d; hd.res_exp = l.res_exp; hd.skip_e = he; hd.redo_slot = redo_slot; hd.status_exps = st_exps;
             hd.enable = fold ? 1 : 0;
-            ResidTail tl{};
-            tl.reps = (more && fold) ? EXT_REPS : 1; // the next layer's B projection derives its exponents from the extremes
-            hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(rm_grid), dim3(RESID_THREADS), 0, st, (const int16_t *)I16(w.z),
-                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, rm_span, l.res_bits, hb, hd, ext_next, tl,
-                               status);
+            const int ext_reps = (more && fold) ? EXT_REPS : 1; // the next layer's B projection derives its exponents from the extremes
+            hipLaunchKernelGGL(k_resid_minmax16<true>, dim3(rm_grid, G), dim3(RESID_THREADS), 0, st, (const int16_t *)I16(w.z),
+                               (const int16_t *)h, hn, tr ? tr->residadd : nullptr, N, H, rm_span, l.res_bits, hb, hd, ext_next, ext_reps,
+                               status, go);
         } else {
             hipLaunchKernelGGL(k_resid16, dim3(ew_grid(NH / 4)), dim3(256), 0, st, (const int16_t *)I16(w.z),
                                (const int16_t *)h, hn, tr ? tr->residadd : nullptr, NH, l.res_bits, hb, (const LayerDyn *)d);

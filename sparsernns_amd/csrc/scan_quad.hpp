@@ -37,6 +37,25 @@ namespace s5 {
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 
+// Grouped launches: one launch of a fused-path kernel may cover several independent reference batches ("groups": every
+// group is its own compute_best batch with its own exponents, status words and streaming carry).  gridDim.y = number of
+// groups, blockIdx.y = this workgroup's group; group g's tensors lie g * stride bytes behind group 0's -- the model input
+// and output, the per-forward workspace (every activation, stream, LayerDyn and extremes buffer lives in it), the
+// status words and the two carry arrays.  Kernels shift their pointers once, at the top.
+struct GroupOff {
+    int64_t x, y, ws, status, state_in, state_out; // byte strides
+};
+template <class P> // P: any (possibly restrict-qualified) pointer type; a null pointer stays null
+__device__ __forceinline__ void gshift(P &p, int64_t bytes)
+{
+    if (p) p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+}
+template <class P> // for pointers that are never null
+__device__ __forceinline__ void gshift_nn(P &p, int64_t bytes)
+{
+    p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+}
+
 // word index of (sequence b, step t, state p, component c) in a scan-native stream with TB blocks/sequence
 __device__ __forceinline__ int64_t native_word(int64_t b, int t, int p, int c, int TB, int P)
 {
@@ -138,8 +157,16 @@ __global__ __launch_bounds__(256) void k_scan_quad(ScanQuadArgs a)
 // buffer_load / buffer_store / s_add instructions (tools/gen_scan_asm.py).  Same algorithm, layout and
 // exactness bound as k_scan_quad.  One wave per workgroup: every wave gets its own CU front end.
 // The stream must be followed by S5_SCAN_ASM_DEPTH blocks of readable padding (the ring runs ahead).
-__global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
+__device__ __forceinline__ void scan_quad_group(ScanQuadArgs &a, const GroupOff &go)
 {
+    const int64_t g = blockIdx.y;
+    gshift(a.bq, g * go.ws); gshift(a.xs, g * go.ws); gshift(a.run_if, g * go.ws);
+    gshift(a.x0_re, g * go.state_in); gshift(a.x0_im, g * go.state_in);
+}
+
+__global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a, GroupOff go)
+{
+    scan_quad_group(a, go);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
     const int groups = a.P >> 4;
@@ -181,8 +208,9 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm(ScanQuadArgs a)
 // input halfword is picked by the SDWA source select, the output is packed with saturation -- a state beyond 16 bits
 // is stored as +-32767 / -32768, which the consumer's range check treats as out of range.  Half the bytes of
 // k_scan_quad_asm on both sides; item = 8 bytes (4 steps of one component), state block = 16 bytes.
-__global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a)
+__global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a, GroupOff go)
 {
+    scan_quad_group(a, go);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
     const int groups = a.P >> 4;
@@ -221,8 +249,9 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a)
 // subtraction as a conditional negation -(a >> e) == ((a >> e) ^ -1) + 1 folded into a three-operand add with Bu.
 // Five dependent instructions per step instead of three, one of them quarter rate: ~50 cycles per step against the
 // one-lane-per-state kernel's ~190 (k_scan_lane_native: 360 us per layer at B=32, L=4096).  int32 streams.
-__global__ __launch_bounds__(64) void k_scan_quad32_asm(ScanQuadArgs a)
+__global__ __launch_bounds__(64) void k_scan_quad32_asm(ScanQuadArgs a, GroupOff go)
 {
+    scan_quad_group(a, go);
     if (a.run_if && *a.run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
@@ -286,8 +315,12 @@ __device__ __forceinline__ int64_t pair_word(int64_t b, int tb, int p, int TB, i
 // carry out).  mode 0: scan-native int32, 1: scan-native int16, 2: pair-native int16.  With redo != nullptr and *redo
 // != 0 the exact re-run has rewritten the stream as scan-native int32 (mode 0) whatever the fast kernel's mode was.
 __global__ void k_state_out(const void *xs, int mode, const int32_t *redo, int B, int L, int P, int TB, int32_t *out_re,
-                            int32_t *out_im)
+                            int32_t *out_im, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(xs, g * go.ws); gshift(redo, g * go.ws); gshift(out_re, g * go.state_out); gshift(out_im, g * go.state_out);
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * P) return;
     const int b = i / P, p = i % P, t = L - 1;
@@ -322,8 +355,12 @@ struct ScanPairArgs {
     const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
 };
 
-__global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a)
+__global__ __launch_bounds__(64) void k_scan_pair_asm(ScanPairArgs a, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.k, g * go.ws); gshift(a.xs, g * go.ws); gshift(a.x0_re, g * go.state_in); gshift(a.x0_im, g * go.state_in);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x); // (b, state group of 32)
     if (wave >= a.B * (a.P >> 5)) return;
@@ -380,8 +417,12 @@ __device__ __forceinline__ void for_items(std::integer_sequence<int, J...>, F f)
 
 // DBG (tools/ubench_pair.hip only): 1 = the helper skips its loads, 2 = it only meets the barriers
 template <int BLOCKS, int DBG = 0> // time blocks per LDS buffer (16 or 32): one s_barrier per BLOCKS * 4 steps; 3 * BLOCKS KB of dynamic LDS
-__global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a)
+__global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a, GroupOff go)
 {
+    {
+        const int64_t g = blockIdx.y;
+        gshift(a.b16, g * go.ws); gshift(a.xs, g * go.ws); gshift(a.x0_re, g * go.state_in); gshift(a.x0_im, g * go.state_in);
+    }
     extern __shared__ __attribute__((aligned(16))) int32_t kbuf[]; // three buffers of BLOCKS KB
     constexpr int BUFW = BLOCKS * 256;                              // words per buffer
     const int lane = threadIdx.x & 63;

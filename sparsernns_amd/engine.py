@@ -61,6 +61,7 @@ class Engine:
         self.level = 0
         self._redos = [0, 0]
         self._wsl: Dict[int, tuple] = {}
+        self._groups: Dict[int, int] = {}   # groups of the last forward enqueued on a lane
         self._cb_keep = None
 
     def __del__(self):
@@ -153,28 +154,37 @@ class Engine:
     def status(self) -> torch.Tensor:
         return self._status[0]
 
-    def lane_status(self, lane: int) -> torch.Tensor:
-        if lane not in self._status:
-            self._status[lane] = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=self.device)
-        return self._status[lane]
+    def lane_status(self, lane: int, groups: int = 1) -> torch.Tensor:
+        """The status words of `lane`: STATUS_WORDS per group, group after group (a plain forward is one group)."""
+        st = self._status.get(lane)
+        if st is None or st.numel() < groups * _lib.STATUS_WORDS:
+            st = self._status[lane] = torch.zeros(groups * _lib.STATUS_WORDS, dtype=torch.int32, device=self.device)
+        return st
 
-    def workspace(self, B: int, L: int, lane: int = 0) -> torch.Tensor:
+    def workspace(self, B: int, L: int, lane: int = 0, groups: int = 1) -> torch.Tensor:
         key, ws = self._wsl.get(lane, (None, None))
-        if key != (B, L):
-            n = lib.s5fxp_workspace_bytes(self._h, B, L)
+        if key != (B, L, groups):
+            n = groups * lib.s5fxp_workspace_bytes(self._h, B, L)
             ws = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._wsl[lane] = ((B, L), ws)
+            self._wsl[lane] = ((B, L, groups), ws)
         return ws
 
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
                 traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
                 scan_events: Optional[list] = None, flags: int = 0, lane: int = 0,
-                state_in: Optional[torch.Tensor] = None, state_out: Optional[torch.Tensor] = None) -> None:
+                state_in: Optional[torch.Tensor] = None, state_out: Optional[torch.Tensor] = None, groups: int = 1) -> None:
         """Launches one forward on the current stream; nothing is synchronised.
+
+        groups = G > 1: x and y hold G * B sequences, G independent reference batches of B sequences each (what G calls
+        would compute: own exponents, status words and carry per group) enqueued as ONE set of kernel launches
+        (include/s5fxp.h, s5fxp_forward_opts::groups).
 
         flags: _lib.FWD_DEFER_REDO drops the (normally idle) gated exact re-run launches -- the caller must then
         read the status words and repeat with _lib.FWD_EXACT when ST_REDO is set (``forward`` does)."""
-        ws = self.workspace(B, L, lane)
+        if groups > 1 and (traces is not None or allreduce is not None):
+            raise ValueError("a grouped forward takes neither traces nor a cross-rank hook: run the groups one by one")
+        ws = self.workspace(B, L, lane, groups)
+        self._groups[lane] = groups
         tr = None
         if traces is not None:
             tr = (LayerTrace * self.n_layers)()
@@ -203,20 +213,27 @@ class Engine:
             opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
             self._ev_keep = arr
         opts.flags = int(flags)
+        opts.groups = int(groups)
+        want = (self.n_layers, 2, B, self.P) if groups == 1 else (groups, self.n_layers, 2, B, self.P)
         for name, t in (("state_in", state_in), ("state_out", state_out)):
             if t is not None:
-                if t.dtype != torch.int32 or tuple(t.shape) != (self.n_layers, 2, B, self.P) or not t.is_contiguous() or not t.is_cuda:
-                    raise ValueError(f"{name} must be a contiguous int32 device tensor of shape (n_layers, 2, B, P)")
+                if t.dtype != torch.int32 or tuple(t.shape) != want or not t.is_contiguous() or not t.is_cuda:
+                    raise ValueError(f"{name} must be a contiguous int32 device tensor of shape {want}")
                 setattr(opts, name, t.data_ptr())
         self._cb_keep = opts
         check(lib.s5fxp_model_forward(self._h, x.data_ptr(), x_bits, x_exp, B, L, y.data_ptr(), ws.data_ptr(),
-                                      ws.numel(), self.lane_status(lane).data_ptr(),
+                                      ws.numel(), self.lane_status(lane, groups).data_ptr(),
                                       C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, C.byref(opts),
                                       torch.cuda.current_stream().cuda_stream), "s5fxp_model_forward")
 
     def check_status(self, lane: int = 0) -> np.ndarray:
-        """Reads the status words back (one sync) and raises what the reference would have raised."""
-        st = self.lane_status(lane).cpu().numpy()
+        """Reads the status words back (one sync) and raises what the reference would have raised.  After a grouped
+        forward word [0] of the returned array carries the error bits of ALL groups (the per-group words follow at
+        multiples of STATUS_WORDS)."""
+        groups = self._groups.get(lane, 1)
+        st = self.lane_status(lane, groups).cpu().numpy()[:groups * _lib.STATUS_WORDS].copy()
+        for g in range(1, groups):
+            st[0] |= st[g * _lib.STATUS_WORDS]
         if st[0] & _lib.ST_NEGSHIFT:
             raise ValueError("invalid result_exp: a data-dependent shift came out negative (fxparray.py:619-621)")
         if st[0] & _lib.ST_NEGEXP:
@@ -262,6 +279,19 @@ class Engine:
         out = FxpArray(y, self.out_bits, self.out_exp, True)
         return (out, tr) if traces else out
 
+
+    def forward_batches(self, x: FxpArray, batch: int) -> FxpArray:
+        """x: (G * batch, L, d_in) -- G independent reference batches of `batch` sequences each (the reference's
+        run_validation loop over a loader, sparseRNNs/fxprun.py:53-88, several batches per call).  Returns what G calls of
+        ``forward`` would, as one (G * batch, L, d_out) FxpArray, from ONE set of kernel launches."""
+        data = x.data.contiguous()
+        if data.ndim != 3 or data.shape[-1] != self.d_in or data.shape[0] % batch:
+            raise ValueError(f"expected (G * {batch}, L, {self.d_in}), got {tuple(data.shape)}")
+        G, L = data.shape[0] // batch, data.shape[1]
+        y = torch.empty(tuple(data.shape[:-1]) + (self.d_out,), dtype=torch.int32, device=data.device)
+        if G * batch * L:
+            self.run_ladder(lambda fl: self.enqueue(data, x.bits, x.exp, y, batch, L, flags=fl, groups=G), self.check_status)
+        return FxpArray(y, self.out_bits, self.out_exp, True)
 
     # -- streaming ------------------------------------------------------------------------------
     def zero_state(self, B: int) -> torch.Tensor:
@@ -334,7 +364,7 @@ class InflightRunner:
         self._lane0 = 1
 
     def submit(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int, check: bool = True,
-               scan_events: Optional[list] = None) -> int:
+               scan_events: Optional[list] = None, groups: int = 1) -> int:
         """check=False skips the status check of the lane's previous batch (only sound when every batch of the lane
         is the same input, as in bench.py: the last check then speaks for all)."""
         lane = self._next
@@ -346,13 +376,13 @@ class InflightRunner:
         level = self.engine.level
         with torch.cuda.stream(s):
             self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=Engine.LEVEL_FLAGS[level], lane=self._lane0 + lane,
-                                scan_events=scan_events)
+                                scan_events=scan_events, groups=groups)
         # the tensors were allocated on another stream: tell the caching allocator that this lane's stream uses them, so
         # that dropping the previous job's references below (check=False) cannot hand their memory out while kernels of
         # this stream still read or write it
         x.record_stream(s)
         y.record_stream(s)
-        self._pending[lane] = (x, x_bits, x_exp, y, B, L, level)
+        self._pending[lane] = (x, x_bits, x_exp, y, B, L, level, groups)
         return lane
 
     def _finish(self, lane: int) -> None:
@@ -362,12 +392,12 @@ class InflightRunner:
         self._pending[lane] = None
         s = self.streams[lane]
         s.synchronize()
-        x, x_bits, x_exp, y, B, L, level = job
+        x, x_bits, x_exp, y, B, L, level, groups = job
         st = self.engine.check_status(self._lane0 + lane)
         while (st[0] & _lib.ST_REDO) and level < 2:   # climb the ladder: pair -> quad -> exact
             level = self.engine.note_redo(level)
             with torch.cuda.stream(s):
-                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=Engine.LEVEL_FLAGS[level], lane=self._lane0 + lane)
+                self.engine.enqueue(x, x_bits, x_exp, y, B, L, flags=Engine.LEVEL_FLAGS[level], lane=self._lane0 + lane, groups=groups)
             s.synchronize()
             st = self.engine.check_status(self._lane0 + lane)
 

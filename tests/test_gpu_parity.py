@@ -158,6 +158,66 @@ def test_ragged_tail_does_not_leak_into_the_range_check():
         assert np.array_equal(y.cpu().numpy(), ref), flags
 
 
+@pytest.mark.parametrize("case", ["ndns05", "ndns10", "generic"])
+def test_grouped_forward_equals_one_forward_per_batch(case):
+    """s5fxp_forward_opts::groups: G reference batches in ONE set of launches (gridDim.y = G) must give, group by group, what
+    G separate forwards give -- each group its own compute_best exponents (the groups get inputs of different scale, so the
+    exponents differ), its own status words, its own streaming carry; ragged L; one group that overflows the fast
+    recurrence takes the whole call down the ladder and the result is still the oracle's.  The generic engine takes the
+    per-group loop behind the same call."""
+    import torch
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    cfg = dict(dim_scale=1.0, calib_L=128) if case == "ndns10" else dict(dim_scale=0.5, calib_L=1024, state_headroom_bits=1)
+    md, qc, dims = _make(cfg)
+    model = build_regression_model(md, qc, dims["n_layers"], engine_flags=_lib.MODEL_FORCE_GENERIC if case == "generic" else 0)
+    eng = model.engine()
+    cm = cref.CModel(model.export())
+    G, B, L = 3, 4, 203 if case != "generic" else 61
+    scales = (1.0, 0.25, 2.0)
+    parts = [_input(qc, dims, B, L, seed=70 + g, scale=scales[g]) for g in range(G)]
+    bits, exp = parts[0].bits, parts[0].exp
+    x = np.concatenate([p.data for p in parts])
+    refs, ref_state = [], np.zeros((G, dims["n_layers"], 2, B, dims["P"]), dtype=np.int32)
+    res_exps = []
+    for g in range(G):
+        r, rb, re_, rtr = cm.forward(parts[g].data, bits, exp, trace=True, state=ref_state[g])
+        refs.append(r)
+        res_exps.append([t["residadd_exp"] for t in rtr])
+    assert len({tuple(e) for e in res_exps}) > 1       # the groups really choose different exponents
+    y = eng.forward_batches(FxpArray(x, bits, exp), B)
+    assert (y.bits, y.exp) == (rb, re_)
+    assert np.array_equal(y.numpy(), np.concatenate(refs))
+    st = eng.lane_status(0, G).cpu().numpy()
+    for g in range(G):
+        w = st[g * _lib.STATUS_WORDS:(g + 1) * _lib.STATUS_WORDS]
+        assert w[2] == (_lib.PATH_GENERIC if case == "generic" else _lib.PATH_FUSED)
+        assert [int(w[8 + 8 * i + 4]) for i in range(dims["n_layers"])] == res_exps[g], g
+    # the carry, group by group
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty((G * B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+    s_in = torch.zeros((G, dims["n_layers"], 2, B, dims["P"]), dtype=torch.int32, device="cuda")
+    s_out = torch.empty_like(s_in)
+    eng.run_ladder(lambda fl: eng.enqueue(xd, bits, exp, yd, B, L, flags=fl, groups=G, state_in=s_in, state_out=s_out), eng.check_status)
+    assert np.array_equal(s_out.cpu().numpy(), ref_state)
+    assert np.array_equal(yd.cpu().numpy(), np.concatenate(refs))
+    if case == "generic":
+        return
+    # one group leaves the fast range: ST_REDO comes back for the call, the ladder repeats it, every group is still right
+    big = _input(qc, dims, B, L, seed=99, scale=40.0)
+    x2 = np.concatenate([parts[0].data, big.data, parts[2].data])
+    rbig, _, _, _ = cm.forward(big.data, bits, exp)
+    eng.level = 0
+    y2 = eng.forward_batches(FxpArray(x2, bits, exp), B)
+    assert np.array_equal(y2.numpy(), np.concatenate([refs[0], rbig, refs[2]]))
+    # and the self-contained form (gated exact kernels enqueued for every group)
+    eng.enqueue(torch.from_numpy(x2).cuda(), bits, exp, yd, B, L, flags=0, groups=G)
+    eng.check_status()
+    assert np.array_equal(yd.cpu().numpy(), np.concatenate([refs[0], rbig, refs[2]]))
+
+
 def test_eager_matches_fused_and_names_intermediates():
     from sparsernns_amd.fxparray import FxpArray
     from sparsernns_amd.fxpmodel import build_regression_model
