@@ -103,7 +103,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
     ap.add_argument("--inflight", type=int, default=3, help="launch sets in flight (streams); 1 = one at a time")
-    ap.add_argument("--groups", type=int, default=4,
+    ap.add_argument("--groups", type=int, default=8,
                     help="reference batches per launch set (s5fxp_forward_opts::groups): G independent batches of --batch sequences, each "
                          "its own compute_best batch, enqueued as one set of kernel launches; a step is still ONE batch")
     ap.add_argument("--no-scan-sweep", action="store_true", help="skip the extra recurrence-kernel measurement at 4x batch")

@@ -279,6 +279,18 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward
  * Results do not depend on any of them. */
 
+/* FxpSequenceLayer.forward, fxpmodel.py:1110-1161, for layer `layer` of a created model -- the unit the reference's
+ * verification walks (fxprun.py:583-727).  x: (B,L,H) int32 device with configuration (x_bits, x_exp); y: (B,L,H) int32
+ * device, s5fxp_model_layer_out_bits() bits at the exponent the residual compute_best add chose: written to
+ * status[8 + 8*layer + 4] and, when y_exp_dev is not NULL, to that device int.  Runs the generic int32 kernels (exact for
+ * any int32 operands) whatever path whole forwards of the model take.  workspace / status / trace (ONE entry) / opts as
+ * s5fxp_model_forward; opts->state_in / state_out here are [2][B][P], the carry of this layer alone; opts->groups must be
+ * 0 or 1. */
+int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_t *x, int x_bits, int x_exp, int B, int L, int32_t *y,
+                        int32_t *y_exp_dev, void *workspace, size_t workspace_bytes, int32_t *status,
+                        const s5fxp_layer_trace *trace, const s5fxp_forward_opts *opts, void *stream);
+int s5fxp_model_layer_out_bits(const s5fxp_model *m, int layer);
+
 /* Static facts about a created model (for INTEGRATION / debugging). */
 int s5fxp_model_out_exp(const s5fxp_model *m);
 int s5fxp_model_out_bits(const s5fxp_model *m);

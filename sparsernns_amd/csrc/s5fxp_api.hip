@@ -610,81 +610,51 @@ extern "C" size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L)
     return g > f ? g : f;
 }
 
-extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L,
-                                   int32_t *y, void *workspace, size_t workspace_bytes, int32_t *status,
-                                   const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, void *stream)
+namespace {
+
+// FxpSequenceLayer.forward (fxpmodel.py:1110-1161) x [first, last) on the generic int32 kernels: BatchNorm exponents
+// (reduce -> cross-rank max -> finalize per compute_best op), B projection, recurrence, C projection (+ exact re-run),
+// out2 / sigmoid / gate, residual.  h: the first layer's input (read only), hn / h: the ping-pong pair the outputs go to;
+// on return h points at the last layer's output and (hb, he) are its configuration.
+struct GenericRun {
+    const s5fxp_model *m;
+    int B, L;
+    WsLayout w;
+    char *ws;
+    LayerDyn *dyn;
+    int32_t *status;
+    const s5fxp_layer_trace *traces; // indexed by layer - trace_base
+    int trace_base;
+    const s5fxp_forward_opts *opts;
+    hipStream_t st;
+    void *stream;
+};
+
+int generic_layers(const GenericRun &g, int first, int last, int32_t *&h, int32_t *&hn, int &hb, DynExp &he)
 {
-    if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
-    const int G = opts && opts->groups > 1 ? opts->groups : 1;
-    const size_t ws_one = s5fxp_workspace_bytes(m, B, L);
-    if (workspace_bytes < (size_t)G * ws_one) return S5FXP_EWORKSPACE;
-    if (G > 1) {
-        // Grouped call: G independent reference batches of B sequences each.  The fused kernels take them in ONE set of
-        // launches (gridDim.y = G) when nothing couples the groups on the host; otherwise one forward per group.
-        if (m->fast && !traces && !opts->allreduce && fast_bn_ext(m) &&
-            (((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 < 0xffffffffll)
-            return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream), G, ws_one);
-        const size_t plane = (size_t)m->n_layers * 2 * B * (m->P ? m->P : 1);
-        for (int g = 0; g < G; ++g) {
-            s5fxp_forward_opts o = *opts;
-            o.groups = 1;
-            if (o.state_in) o.state_in += g * plane;
-            if (o.state_out) o.state_out += g * plane;
-            const int rc = s5fxp_model_forward(m, x + (size_t)g * B * L * m->d_in, x_bits, x_exp, B, L, y + (size_t)g * B * L * m->d_out,
-                                               reinterpret_cast<char *>(workspace) + g * ws_one, ws_one, status + (size_t)g * S5FXP_STATUS_WORDS,
-                                               traces ? traces + (size_t)g * m->n_layers : nullptr, &o, stream);
-            if (rc) return rc;
-        }
-        return S5FXP_OK;
-    }
-    // the recurrence kernels address one (sequence, state group) run of a stream through a 32-bit buffer extent
-    if ((((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 >= 0xffffffffll) return S5FXP_EBADARG;
-    if (m->fast) return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
-    s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
-    void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
-    void **scan_events = opts ? opts->scan_events : nullptr;
-    const int32_t *state_in = opts ? opts->state_in : nullptr;
-    int32_t *state_out = opts ? opts->state_out : nullptr;
-    const WsLayout w = ws_layout(m, B, L);
-    if (workspace_bytes < w.total) return S5FXP_EWORKSPACE;
-    hipStream_t st = S(stream);
-    char *ws = reinterpret_cast<char *>(workspace);
+    const s5fxp_model *m = g.m;
+    const int B = g.B, L = g.L;
+    const WsLayout &w = g.w;
+    char *ws = g.ws;
+    LayerDyn *dyn = g.dyn;
+    int32_t *status = g.status;
+    const s5fxp_layer_trace *traces = g.traces;
+    hipStream_t st = g.st;
+    void *stream = g.stream;
+    s5fxp_allreduce_max_fn allreduce = g.opts ? g.opts->allreduce : nullptr;
+    void *allreduce_ctx = g.opts ? g.opts->allreduce_ctx : nullptr;
+    void **scan_events = g.opts ? g.opts->scan_events : nullptr;
+    const int32_t *state_in = g.opts ? g.opts->state_in : nullptr;
+    int32_t *state_out = g.opts ? g.opts->state_out : nullptr;
     auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
-    LayerDyn *dyn = reinterpret_cast<LayerDyn *>(ws + w.dyn);
     const int64_t N = (int64_t)B * L;
     const int H = m->H, P = m->P;
     const int64_t NH = N * H;
     const unsigned tiles = (unsigned)((N + TN - 1) / TN);
     int rc;
-    {
-        StatusInit si{};
-        si.path = S5FXP_PATH_GENERIC;
-        for (int li = 0; li < m->n_layers; ++li)
-            si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
-        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
-    }
-    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1), st)))) return rc;
-
-    // ---- encoder + ReLU (fxpmodel.py:1263-1266)
-    int32_t *h = I(w.hA), *hn = I(w.hB);
-    {
-        const DenseDev &e = m->enc;
-        DenseArgs a{};
-        a.x = x; a.w = e.w; a.bias = e.bias; a.y = h; a.N = N; a.K = e.K; a.M = e.M; a.mw = mw_for(e.M);
-        a.xb = x_bits; a.xe = DynExp{x_exp, nullptr}; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.check_inp = 1;
-        a.w_exp = e.w_exp; a.b_bits = e.b_bits; a.b_exp = e.b_exp; a.out_bits = e.out_bits; a.out_exp = e.out_exp;
-        a.relu = 1; a.check24 = 1; a.status = status;
-        const bool conv = x_bits > e.inp_bits || x_exp > e.inp_exp;
-        if (!shift_ok((conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp)) return S5FXP_ENEGSHIFT;
-        if (e.x24) S5_DISPATCH_MW(a.mw, true, k_dense, tiles, st, a);
-        else S5_DISPATCH_MW(a.mw, false, k_dense, tiles, st, a);
-    }
-    int hb = m->enc.out_bits;
-    DynExp he{m->enc.out_exp, nullptr};
-
-    for (int li = 0; li < m->n_layers; ++li) {
+    for (int li = first; li < last; ++li) {
         const LayerDev &l = m->layers[li];
-        const s5fxp_layer_trace *tr = traces ? &traces[li] : nullptr;
+        const s5fxp_layer_trace *tr = traces ? &traces[li - g.trace_base] : nullptr;
         LayerDyn *d = dyn + li;
         int32_t *st_exps = status + 8 + 8 * li;
         const s5fxp_ssm_desc &s = l.sd;
@@ -810,6 +780,89 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         he = DynExp{0, &d->res.eo};
     }
 
+    (void)rc;
+    return S5FXP_OK;
+}
+
+} // namespace
+
+extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, int B, int L,
+                                   int32_t *y, void *workspace, size_t workspace_bytes, int32_t *status,
+                                   const s5fxp_layer_trace *traces, const s5fxp_forward_opts *opts, void *stream)
+{
+    if (!m || !x || !y || !workspace || !status || B < 1 || L < 1 || x_bits < 1 || x_bits > 32) return S5FXP_EBADARG;
+    const int G = opts && opts->groups > 1 ? opts->groups : 1;
+    const size_t ws_one = s5fxp_workspace_bytes(m, B, L);
+    if (workspace_bytes < (size_t)G * ws_one) return S5FXP_EWORKSPACE;
+    if (G > 1) {
+        // Grouped call: G independent reference batches of B sequences each.  The fused kernels take them in ONE set of
+        // launches (gridDim.y = G) when nothing couples the groups on the host; otherwise one forward per group.
+        if (m->fast && !traces && !opts->allreduce && fast_bn_ext(m) &&
+            (((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 < 0xffffffffll)
+            return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream), G, ws_one);
+        const size_t plane = (size_t)m->n_layers * 2 * B * (m->P ? m->P : 1);
+        for (int g = 0; g < G; ++g) {
+            s5fxp_forward_opts o = *opts;
+            o.groups = 1;
+            if (o.state_in) o.state_in += g * plane;
+            if (o.state_out) o.state_out += g * plane;
+            const int rc = s5fxp_model_forward(m, x + (size_t)g * B * L * m->d_in, x_bits, x_exp, B, L, y + (size_t)g * B * L * m->d_out,
+                                               reinterpret_cast<char *>(workspace) + g * ws_one, ws_one, status + (size_t)g * S5FXP_STATUS_WORDS,
+                                               traces ? traces + (size_t)g * m->n_layers : nullptr, &o, stream);
+            if (rc) return rc;
+        }
+        return S5FXP_OK;
+    }
+    // the recurrence kernels address one (sequence, state group) run of a stream through a 32-bit buffer extent
+    if ((((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 >= 0xffffffffll) return S5FXP_EBADARG;
+    if (m->fast) return forward_fast(m, x, x_bits, x_exp, B, L, y, workspace, status, traces, opts, S(stream));
+    s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
+    void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
+    void **scan_events = opts ? opts->scan_events : nullptr;
+    const int32_t *state_in = opts ? opts->state_in : nullptr;
+    int32_t *state_out = opts ? opts->state_out : nullptr;
+    const WsLayout w = ws_layout(m, B, L);
+    if (workspace_bytes < w.total) return S5FXP_EWORKSPACE;
+    hipStream_t st = S(stream);
+    char *ws = reinterpret_cast<char *>(workspace);
+    auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+    LayerDyn *dyn = reinterpret_cast<LayerDyn *>(ws + w.dyn);
+    const int64_t N = (int64_t)B * L;
+    const int H = m->H, P = m->P;
+    const int64_t NH = N * H;
+    const unsigned tiles = (unsigned)((N + TN - 1) / TN);
+    int rc;
+    {
+        StatusInit si{};
+        si.path = S5FXP_PATH_GENERIC;
+        for (int li = 0; li < m->n_layers; ++li)
+            si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
+    }
+    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1), st)))) return rc;
+
+    // ---- encoder + ReLU (fxpmodel.py:1263-1266)
+    int32_t *h = I(w.hA), *hn = I(w.hB);
+    {
+        const DenseDev &e = m->enc;
+        DenseArgs a{};
+        a.x = x; a.w = e.w; a.bias = e.bias; a.y = h; a.N = N; a.K = e.K; a.M = e.M; a.mw = mw_for(e.M);
+        a.xb = x_bits; a.xe = DynExp{x_exp, nullptr}; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.check_inp = 1;
+        a.w_exp = e.w_exp; a.b_bits = e.b_bits; a.b_exp = e.b_exp; a.out_bits = e.out_bits; a.out_exp = e.out_exp;
+        a.relu = 1; a.check24 = 1; a.status = status;
+        const bool conv = x_bits > e.inp_bits || x_exp > e.inp_exp;
+        if (!shift_ok((conv ? e.inp_exp : x_exp) + e.w_exp - e.out_exp)) return S5FXP_ENEGSHIFT;
+        if (e.x24) S5_DISPATCH_MW(a.mw, true, k_dense, tiles, st, a);
+        else S5_DISPATCH_MW(a.mw, false, k_dense, tiles, st, a);
+    }
+    int hb = m->enc.out_bits;
+    DynExp he{m->enc.out_exp, nullptr};
+
+    {
+        GenericRun g{m, B, L, w, ws, dyn, status, traces, 0, opts, st, stream};
+        if ((rc = generic_layers(g, 0, m->n_layers, h, hn, hb, he))) return rc;
+    }
+
     // ---- decoder (fxpmodel.py:1437): its input exponent is the last residual's
     {
         const DenseDev &e = m->dec;
@@ -822,6 +875,49 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         else S5_DISPATCH_MW(a.mw, false, k_dense, tiles, st, a);
     }
     return launch_rc();
+}
+
+// FxpSequenceLayer.forward for ONE layer of a created model (fxpmodel.py:1110-1161): BatchNorm -> SSM -> ReLU -> out2 ->
+// sigmoid -> gate -> residual compute_best add -> ReLU, on the generic int32 kernels (exact for any int32 operands; the
+// fused kernels exist for whole forwards, where the int16 inter-kernel planes pay off).
+extern "C" int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_t *x, int x_bits, int x_exp, int B, int L,
+                                   int32_t *y, int32_t *y_exp_dev, void *workspace, size_t workspace_bytes, int32_t *status,
+                                   const s5fxp_layer_trace *trace, const s5fxp_forward_opts *opts, void *stream)
+{
+    if (!m || !x || !y || !workspace || !status || layer < 0 || layer >= m->n_layers || B < 1 || L < 1 || x_bits < 1 || x_bits > 32)
+        return S5FXP_EBADARG;
+    if (opts && opts->groups > 1) return S5FXP_EUNSUPPORTED;
+    if ((((int64_t)L + 3) / 4 + 2 * SCAN_DEPTH) * (m->P ? m->P : 1) * 32 >= 0xffffffffll) return S5FXP_EBADARG;
+    const WsLayout w = ws_layout(m, B, L);
+    if (workspace_bytes < w.total) return S5FXP_EWORKSPACE;
+    hipStream_t st = S(stream);
+    char *ws = reinterpret_cast<char *>(workspace);
+    LayerDyn *dyn = reinterpret_cast<LayerDyn *>(ws + w.dyn);
+    int rc;
+    {
+        StatusInit si{};
+        si.path = S5FXP_PATH_GENERIC;
+        si.rk[layer] = m->layers[layer].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+        hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
+    }
+    if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)m->n_layers, st)))) return rc;
+    // streaming carry of a single layer: the arrays are [1][2][B][P] here
+    s5fxp_forward_opts o{};
+    if (opts) o = *opts;
+    const size_t plane2 = (size_t)2 * B * (m->P ? m->P : 1);
+    if (o.state_in) o.state_in -= (size_t)layer * plane2;   // generic_layers indexes the carry by layer
+    if (o.state_out) o.state_out -= (size_t)layer * plane2;
+    int32_t *h = const_cast<int32_t *>(x), *hn = y; // h is only read
+    int hb = x_bits;
+    DynExp he{x_exp, nullptr};
+    GenericRun g{m, B, L, w, ws, dyn, status, trace, layer, &o, st, stream};
+    if ((rc = generic_layers(g, layer, layer + 1, h, hn, hb, he))) return rc;
+    if (y_exp_dev && (rc = hip_rc(hipMemcpyAsync(y_exp_dev, he.dyn, sizeof(int32_t), hipMemcpyDeviceToDevice, st)))) return rc;
+    return launch_rc();
+}
+extern "C" int s5fxp_model_layer_out_bits(const s5fxp_model *m, int layer)
+{
+    return m && layer >= 0 && layer < m->n_layers ? m->layers[layer].res_bits : -1;
 }
 
 #ifdef S5_PHASE_PROF

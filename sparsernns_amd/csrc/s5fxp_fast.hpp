@@ -310,8 +310,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
     // workgroups per launch (persistent loops over tiles): tuned per kernel on MI355X (256 CUs); ModelCfg (S5FXP_WGS_* at
     // model creation) overrides them
-    const int64_t cap_enc = cfg.cap_enc, cap_dec = cfg.cap_dec, cap_cgate = cfg.cap_cgate, cap_bproj = cfg.cap_bproj,
-                  cap_resid = cfg.cap_resid;
+    // A grouped launch shares the caps between its groups (every workgroup pays its prologue once -- weights into registers,
+    // tables into LDS, the exponent derivation -- and G x 512 workgroups of 4 tiles each pay it 4 times as often as 512
+    // workgroups of 16 tiles: tools/sweep_groups.sh, +4 % at G = 4), down to a floor that still fills the chip with G groups
+    auto per_group = [&](int64_t cap, int64_t floor_) { return G > 1 ? std::max<int64_t>(cap / G, floor_) : cap; };
+    const int64_t cap_enc = per_group(cfg.cap_enc, 64), cap_dec = per_group(cfg.cap_dec, 64), cap_cgate = per_group(cfg.cap_cgate, 64),
+                  cap_bproj = per_group(cfg.cap_bproj, 128), cap_resid = per_group(cfg.cap_resid, 64);
     // six-wave phase-split kernels (proj_p.hpp, mfma_fused.hpp): 64-frame tiles
     const int64_t tiles64 = (N + 63) / 64;
     auto grid_for = [&](int64_t tiles, int64_t cap) {

@@ -280,6 +280,34 @@ class Engine:
         return (out, tr) if traces else out
 
 
+    def layer_forward(self, layer: int, x: FxpArray, traces: bool = False):
+        """One ``FxpSequenceLayer.forward`` (sparseRNNs/fxpmodel.py:1110-1161) through ``s5fxp_layer_forward``: x is the
+        layer's input (B,L,H) or (L,H) with its own bits / exponent; returns the layer's output FxpArray (its exponent is the
+        one the residual compute_best add chose on the device), and the layer's traces when asked."""
+        data = x.data.contiguous()
+        if data.shape[-1] != self.H:
+            raise ValueError(f"expected last dim {self.H}, got {tuple(data.shape)}")
+        B, L = (1, data.shape[0]) if data.ndim == 2 else (data.shape[0], data.shape[1])
+        y = torch.empty_like(data)
+        ws = self.workspace(B, L)
+        self._groups[0] = 1
+        tr, d = None, None
+        if traces:
+            tr = (LayerTrace * 1)()
+            d = {}
+            for k in TRACE_FIELDS:
+                wd = self.P if k in ("Bu_re", "Bu_im", "xs_re", "xs_im") else self.H
+                d[k] = torch.empty(tuple(data.shape[:-1]) + (wd,), dtype=torch.int32, device=data.device)
+                setattr(tr[0], k, d[k].data_ptr())
+        e = torch.zeros(1, dtype=torch.int32, device=data.device)
+        check(lib.s5fxp_layer_forward(self._h, layer, data.data_ptr(), x.bits, x.exp, B, L, y.data_ptr(), e.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), self.lane_status(0).data_ptr(),
+                                      C.cast(tr, C.POINTER(LayerTrace)) if tr is not None else None, None,
+                                      torch.cuda.current_stream().cuda_stream), "s5fxp_layer_forward")
+        self.check_status()
+        out = FxpArray(y, lib.s5fxp_model_layer_out_bits(self._h, layer), int(e.item()), True)
+        return (out, d) if traces else out
+
     def forward_batches(self, x: FxpArray, batch: int) -> FxpArray:
         """x: (G * batch, L, d_in) -- G independent reference batches of `batch` sequences each (the reference's
         run_validation loop over a loader, sparseRNNs/fxprun.py:53-88, several batches per call).  Returns what G calls of

@@ -16,8 +16,17 @@ replaced by interchange files this repo can read:
                          trees: modeldict and fxp_qconfig are derived exactly as
                          ``fxprun.py:294-397`` derives them (sparsernns_amd/fxputils.py), then the model is built from them
   --inputs X.npy         float32 (B,L,d_in) model inputs (the reference's ``inputs.npy``); default: synthetic
+  --verify [--activations A.npz] [--report DIR]
+                         ``run_verification`` (fxprun.py:476-731): the op-by-op forward with ``store_intermediates``, checked
+                         against the fused engine bit for bit, then every stage the reference's report looks at is compared
+                         with the FLOAT model's activation of that stage (abs / rel error, sparsernns_amd/fxpreporter.py).
+                         A.npz is the float side as an npz tree (the reference's ``activations_fp.pkl`` through
+                         tools/reference_pickles_to_npz.py); without it the float forward of this package runs on the
+                         same float parameters (--synthetic, --params)
 
-Flags kept from the reference where they mean the same: --quantization, --seq_len, --bsz, --export.
+Flags kept from the reference where they mean the same (fxprun.py:98-269): --quantization, --seq_len, --bsz, --export,
+--separate_exponents, and --params_fname / --stats_fname / --inputs_fname / --activations_fname as aliases of the file
+options above (here they are paths, not names inside a checkpoint directory).
 There is no CPU fallback: without a ROCm GPU and the built libs5fxp.so this exits with an error.
 """
 from __future__ import annotations
@@ -66,11 +75,16 @@ def main(argv=None) -> int:
     src = ap.add_mutually_exclusive_group(required=True)
     src.add_argument("--synthetic", action="store_true")
     src.add_argument("--model", type=str, help="integer model, export() layout (.npz)")
-    src.add_argument("--params", type=str, help="calibrated float parameters as an npz tree (needs --stats)")
-    ap.add_argument("--stats", type=str, help="calibration statistics as an npz tree (with --params)")
+    src.add_argument("--params", "--params_fname", dest="params", type=str, help="calibrated float parameters as an npz tree (needs --stats)")
+    ap.add_argument("--stats", "--stats_fname", dest="stats", type=str, help="calibration statistics as an npz tree (with --params)")
     ap.add_argument("--separate_exponents", action="store_true", help="per-layer exponents, as the reference's flag (with --params)")
     ap.add_argument("--meta", type=str, help="json beside --model (export_qconfig, input bits/exp)")
-    ap.add_argument("--inputs", type=str, default=None, help="float32 (B,L,d_in) .npy")
+    ap.add_argument("--inputs", "--inputs_fname", dest="inputs", type=str, default=None, help="float32 (B,L,d_in) .npy")
+    ap.add_argument("--activations", "--activations_fname", dest="activations", type=str, default=None,
+                    help="--verify: the float model's intermediates of sequence 0 as an npz tree (fxpreporter.verification_report)")
+    ap.add_argument("--report", type=str, default=None, help="--verify: write report.md / results.json into this folder")
+    ap.add_argument("--write-activations", type=str, default=None,
+                    help="--verify without --activations: save the float intermediates this run computed (npz tree)")
     ap.add_argument("--outputs", type=str, default=None, help="write the float outputs here (.npy)")
     ap.add_argument("--quantization", type=str, default="w8a16")
     ap.add_argument("--dim_scale", type=float, default=0.5)
@@ -81,11 +95,12 @@ def main(argv=None) -> int:
     ap.add_argument("--steps", type=int, default=10, help="timed forwards")
     ap.add_argument("--inflight", type=int, default=1, help="batches kept in flight (engine.InflightRunner)")
     ap.add_argument("--verify", action="store_true",
-                    help="run_verification: op-by-op forward with store_intermediates, compared with the fused engine")
+                    help="run_verification: op-by-op forward with store_intermediates, compared with the fused engine and, stage by "
+                         "stage, with the float model's activations")
     ap.add_argument("--export", type=str, default=None, help="write the integer model as PREFIX.npz / PREFIX.json")
     ap.add_argument("--check-golden", action="store_true",
                     help="--model only: the npz also holds an integer input `x` and the output `y` some other implementation "
-                         "produced for it (the reference's fxpmodel_io.pkl through tools/convert_reference_export.py, or "
+                         "produced for it (the reference's fxpmodel_io.pkl through tools/reference_pickles_to_npz.py export, or "
                          "tests/golden/*.npz): run x and compare bit for bit")
     args = ap.parse_args(argv)
 
@@ -170,6 +185,23 @@ def main(argv=None) -> int:
             print(f"[fxprun]   layer {i} intermediates: {', '.join(names)}")
         if not same:
             return 1
+        # ---- fixed point vs float, stage by stage (fxprun.py:553-731, fxpreporter.py)
+        from . import fxputils
+        from .fxpreporter import Reporter, verification_report
+        if args.activations:
+            acts = fxputils.load_tree_npz(args.activations)
+        else:
+            acts = {}
+            synth.float_forward(md, x[:1], dims["n_layers"], activations=acts)
+            if args.write_activations:
+                fxputils.save_tree_npz(args.write_activations, acts)
+        rep = Reporter(args.report, header=dict(quantization=args.quantization, batch=B, seq_len=L, input_bits=inp_bits, input_exp=inp_exp,
+                                                float_side=args.activations or "sparsernns_amd.synth.float_forward"))
+        verification_report(eager, FxpArray(fx.data[:1], fx.bits, fx.exp), x[0], acts, rep, seq_len=L)
+        rep.save()
+        w = rep.worst()
+        print(f"[fxprun] verification report: {len(rep.results_data)} stages; largest median relative error {w['rel_error_med']:.3%} "
+              f"at {w['name']}" + (f"; written to {args.report}/report.md" if args.report else ""))
 
     if args.export:
         ex = (model.export() if model is not None else export)

@@ -146,8 +146,11 @@ def zoh(mixer: dict):
 
 
 def float_forward(modeldict: dict, x: np.ndarray, n_layers: int, calibrate_bn: bool = False,
-                  stats: Optional[dict] = None) -> np.ndarray:
-    """x: (B,L,d_in) float32.  Records absmax observers into ``stats`` when given."""
+                  stats: Optional[dict] = None, activations: Optional[dict] = None) -> np.ndarray:
+    """x: (B,L,d_in) float32.  Records absmax observers into ``stats`` when given, and -- for the verification report
+    (sparsernns_amd/fxpreporter.py) -- the float intermediates of sequence 0 into ``activations`` under the keys the
+    reference's float model sows (sparseRNNs/model/layers.py:181-243: input, pre_s5, pre_C, pre_GLU, out2/__call__, the
+    layer's __call__; ssm.py: mixer/__call__, B_bar; post_GLU = the second drop/__call__ that fxprun.py:688-698 reads)."""
 
     def obs(key, v):
         if stats is not None:
@@ -158,9 +161,11 @@ def float_forward(modeldict: dict, x: np.ndarray, n_layers: int, calibrate_bn: b
     h = x @ enc["encoder"]["kernel"] + enc["encoder"]["bias"]
     obs("encoder.out", h)
     h = np.maximum(h, 0)
+    act_enc = activations.setdefault("encoder", {}) if activations is not None else None
     for i in range(n_layers):
         layer = enc[f"layers_{i}"]
         skip = h
+        act = act_enc.setdefault(f"layers_{i}", {}) if act_enc is not None else None
         nm = layer["norm"]
         if calibrate_bn:
             nm["mean"] = h.mean(axis=(0, 1)).astype(F32)
@@ -194,9 +199,16 @@ def float_forward(modeldict: dict, x: np.ndarray, n_layers: int, calibrate_bn: b
         obs(f"l{i}.gate.l", x1)
         obs(f"l{i}.gate.r", g)
         h = np.maximum(x1 * g + skip, 0).astype(F32)
+        if act is not None:
+            act.update(input=skip[0].astype(F32), pre_s5=u[0].astype(F32), pre_C=xs[0].astype(np.complex64), pre_GLU=y[0].astype(F32),
+                       post_GLU=(x1 * g)[0].astype(F32), __call__=h[0])
+            act["mixer"] = dict(B_bar=B_bar.astype(np.complex64), __call__=y[0].astype(F32))
+            act["out2"] = dict(__call__=g_in[0].astype(F32))
     obs("decoder.inp", h)
     out = h @ modeldict["decoder"]["kernel"] + modeldict["decoder"]["bias"]
     obs("decoder.out", out)
+    if activations is not None:
+        activations["__call__"] = out[0].astype(F32)
     return out.astype(F32)
 
 

@@ -514,6 +514,21 @@ def test_fxputils_separate_exponents_and_batchnorm_scale_quirk():
     assert isinstance(joined["blocks"]["ssm"]["activations"]["u"]["fracbits"], list) and "layers_0" in full["blocks"]["ssm"]
 
 
+def test_reporter_metrics_follow_the_reference_definitions():
+    """sparseRNNs/fxpreporter.py:12-24: absolute error over everything, relative error over the elements whose float value is
+    not zero; complex stages are reported per part (:137-171)."""
+    from sparsernns_amd.fxpreporter import Reporter, compute_error
+
+    m = compute_error(xrec=np.array([1.0, 2.5, 0.0, -4.0]), xhat=np.array([1.0, 2.0, 0.0, -5.0]))
+    assert m["abs_error_mean"] == 0.375 and m["abs_error_max"] == 1.0 and m["abs_error_med"] == 0.25
+    assert abs(m["rel_error_mean"] - 0.15) < 1e-12 and m["rel_error_max"] == 0.25 and abs(m["rel_error_med"] - 0.2) < 1e-12
+    r = Reporter(None)
+    r.add_block_raw("z", xhat=np.array([1 + 2j, 3 - 1j]), xrec=np.array([1 + 2j, 3 - 2j]), verbose=False)
+    assert [b["name"] for b in r.results_data] == ["z (real)", "z (imag)"]
+    assert r.results_data[0]["abs_error_max"] == 0.0 and r.results_data[1]["abs_error_max"] == 1.0
+    assert "| z (imag) |" in r.markdown()
+
+
 def test_pickle_converter_reads_array_trees_only(tmp_path):
     """tools/reference_pickles_to_npz.py (the run-elsewhere step in front of fxputils): pickles written HERE by this test --
     NumPy trees shaped like the reference's calibration output -- convert to the npz pair fxputils reads, and a pickle that
@@ -539,6 +554,22 @@ def test_pickle_converter_reads_array_trees_only(tmp_path):
     evil = pickle.dumps({"x": os.getcwd})  # a global that is not an array constructor
     with pytest.raises(pickle.UnpicklingError):
         conv.load_arrays_only(evil)
+    with pytest.raises(pickle.UnpicklingError):  # nor does living under "numpy." make a callable an array constructor
+        conv.load_arrays_only(pickle.dumps({"x": np.testing.assert_equal}))
+    # activations_fp.pkl (lists of recorded calls, batch first) -> the per-stage tree of the verification report
+    acts = {}
+    xs = synth.make_input(2, 24, dims["d_in"], seed=3)
+    synth.float_forward(md, xs, dims["n_layers"], activations=acts)
+    rec = {"__call__": [acts["__call__"][None]], "encoder": {}}
+    for name, a in acts["encoder"].items():
+        rec["encoder"][name] = {k: [a[k][None]] for k in ("input", "pre_s5", "pre_C", "pre_GLU", "__call__")}
+        rec["encoder"][name]["mixer"] = {"B_bar": [a["mixer"]["B_bar"]], "__call__": [(a["mixer"]["__call__"][None], a["pre_C"][None])]}
+        rec["encoder"][name]["out2"] = {"__call__": [a["out2"]["__call__"][None]]}
+        rec["encoder"][name]["drop"] = {"__call__": [a["pre_GLU"][None], a["post_GLU"][None]]}
+    with open(folder / "activations_fp.pkl", "wb") as f:
+        pickle.dump(rec, f)
+    assert conv.main(["acts", str(folder / "activations_fp.pkl"), str(tmp_path / "a.npz")]) == 0
+    tree_equal(fxputils.load_tree_npz(tmp_path / "a.npz"), acts, "activations")
     # the exported-integer-model form
     m = O.RegressionModel(md, synth.derive_qconfig(md, stats, dims["n_layers"]), dims["n_layers"])
     with open(folder / "fxpmodel.pkl", "wb") as f:

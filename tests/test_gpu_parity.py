@@ -661,7 +661,7 @@ def test_forward_is_capturable_in_a_hip_graph():
 
 @pytest.mark.parametrize("name", ["tiny_a", "tiny_b_bnscale", "ndns05_short"])
 def test_fxprun_cli_golden_check(name):
-    """--check-golden on the committed fixtures (the same format tools/convert_reference_export.py writes from the
+    """--check-golden on the committed fixtures (the same format tools/reference_pickles_to_npz.py writes from the
     reference's own --export files)."""
     import os
     from sparsernns_amd import fxprun
@@ -964,6 +964,63 @@ def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
     assert np.array_equal(y0.numpy(), eng.forward(FxpArray(fx.data, fx.bits, fx.exp)).numpy())
     with pytest.raises(ValueError):
         eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), torch.zeros((1, 2, B, dims["P"]), dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("case", ["tiny_bnsb", "ndns05"])
+def test_layer_forward_entry_point_matches_the_oracle_layer_by_layer(case):
+    """s5fxp_layer_forward (FxpSequenceLayer.forward, fxpmodel.py:1110-1161): feeding the oracle's
+    ``layer_{i-1}_output`` into layer i must reproduce the oracle's residadd / output of that layer and its data-dependent
+    exponent, for every layer, with the traced stages equal too."""
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    cfg, B, L, scale = CASES[case]
+    md, qc, dims = _make(cfg)
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    fx = _input(qc, dims, B, L, seed=11, scale=scale)
+    om = O.RegressionModel(md, qc, dims["n_layers"])
+    inter = {}
+    om(fx, inter)
+    fl = O.flatten_intermediates(inter)
+    _, _, _, rtr = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp, trace=True)
+    h = fl["encoder_output_relu"]
+    for i in range(dims["n_layers"]):
+        want = fl[f"layers_{i}.output"]
+        got, tr = eng.layer_forward(i, FxpArray(h.data, h.bits, h.exp), traces=True)
+        assert (got.bits, got.exp) == (want.bits, want.exp), (i, got.bits, got.exp, want.bits, want.exp)
+        assert np.array_equal(got.numpy(), want.data), i
+        for k, ck in TRACE_MAP.items():
+            assert np.array_equal(tr[k].cpu().numpy(), rtr[i][ck]), (i, k)
+        h = want
+
+
+def test_fxprun_verify_reports_every_stage_against_float_activations(tmp_path, capsys):
+    """run_verification's report (sparseRNNs/fxprun.py:553-731, fxpreporter.py) -- every stage the reference
+    looks at, fixed point against FLOAT activations, not the repository against itself.  The float side is this package's
+    float forward of the same parameters (what the reference's activations_fp.pkl holds), once computed in the run and once
+    read back from the npz tree the converter writes."""
+    import json
+    from sparsernns_amd import fxprun
+
+    common = ["--synthetic", "--seq_len", "256", "--bsz", "2", "--steps", "0", "--verify"]
+    assert fxprun.main(common + ["--report", str(tmp_path / "r1"), "--write-activations", str(tmp_path / "a.npz")]) == 0
+    out = capsys.readouterr().out
+    assert "op-by-op forward == fused forward: True" in out and "verification report: 41 stages" in out
+    res = json.load(open(tmp_path / "r1" / "results.json"))["results"]
+    names = [r["name"] for r in res]
+    assert names[0] == "inputs" and names[-1] == "decoder" and "encoder.layers_1.mixer.xt (imag)" in names
+    assert "encoder.encoder (post-relu)" in names and "encoder.layers_2.mixer.residadd" in names
+    by = {r["name"]: r for r in res}
+    assert by["inputs"]["abs_error_max"] <= 2.0 ** -15          # FLOOR to 16 bits at exponent 15 (fxprun.py:69-75)
+    for r in res:                                               # w8a16 tracks the float model closely at every stage
+        assert np.isfinite(r["abs_error_mean"]) and r["abs_error_mean"] < 0.02 * r["xhat_absmax"], r
+    assert by["decoder"]["rel_error_med"] < 0.25 and by["encoder.encoder (post-relu)"]["rel_error_med"] < 0.05
+    assert (tmp_path / "r1" / "report.md").read_text().count("\n| ") >= 41
+    # the same report from the activations file
+    assert fxprun.main(common + ["--activations_fname", str(tmp_path / "a.npz"), "--report", str(tmp_path / "r2")]) == 0
+    res2 = json.load(open(tmp_path / "r2" / "results.json"))["results"]
+    assert [r["abs_error_mean"] for r in res2] == [r["abs_error_mean"] for r in res]
 
 
 def test_fxprun_cli_from_calibration_trees(tmp_path):
