@@ -22,6 +22,14 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 GOLDEN = ["tiny_a", "tiny_b_bnscale", "ndns05_short"]
 
 
+
+def _free_port() -> int:
+    """A rendezvous port nobody holds right now (a fixed one collides when two test runs share a host)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def unflatten(flat):
     tree = {}
     for k, v in flat.items():
@@ -322,7 +330,7 @@ dist.destroy_process_group()
 def test_two_rank_protocol_over_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]

@@ -820,6 +820,14 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port() -> int:
+    """A rendezvous port nobody holds right now (a fixed one collides when two test runs share a host)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_engine_ranks_with_global_exponents_equal_one_oracle_run(tmp_path):
     """SURVEY.md 8(e) mode A on the product: two fresh processes (gloo, both on GPU 0), each running Engine.forward
     on its half of the batch with the exponent all-reduce hook; the gathered output must equal ONE oracle run over the
@@ -833,7 +841,7 @@ def test_two_engine_ranks_with_global_exponents_equal_one_oracle_run(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "mode_a_worker.py"
     script.write_text(MODE_A_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", OMP_NUM_THREADS="8")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="8")
     procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -858,16 +866,21 @@ def test_bench_starts_its_own_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["S5FXP_BENCH_BACKEND"] = "gloo"
     small = ["--seq-len", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-scan-sweep"]
-    for extra, n_bl in ((["--batch", "2"], 2 * 2 * 256), (["--config", "3", "--batch", "4", "--global-exponents"], 4 * 256)):
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small + extra, cwd=root, env=env,
+    # two ranks, then four (the launch path of the driver's 8-rank run beyond N = 2: shard_bounds with a remainder-free
+    # split, the gather of four shards, every rank's own clock in the line); config 3 = ONE batch sharded, mode A
+    for n, extra, n_bl in ((2, ["--batch", "2"], 2 * 2 * 256), (2, ["--config", "3", "--batch", "4", "--global-exponents"], 4 * 256),
+                           (4, ["--batch", "2"], 4 * 2 * 256), (4, ["--config", "3", "--batch", "8", "--global-exponents"], 8 * 256)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)] + small + extra, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]
         out = json.loads(lines[0])
-        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["output_gather_ms"] is not None
+        assert out["n_gpus"] == n and out["steps"] == 2 and out["output_gather_ms"] is not None
         assert abs(out["value"] * out["ms_per_step"] * 1e-3 - n_bl) < 1e-3 * n_bl  # value = all ranks' frames / time
         assert out["roofline"]["frac"] > 0 and out["scaling"] == ("strong" if "--config" in extra else "weak")
+        rv = out["rank_values"]
+        assert len(rv["per_rank"]) == n and rv["min"] <= rv["max"] and abs(rv["min"] * n - out["value"]) < 1e-6 * out["value"]
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + small, cwd=root,
                          env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stdout + bad.stderr)
@@ -1013,9 +1026,13 @@ def test_fxprun_verify_reports_every_stage_against_float_activations(tmp_path, c
     assert "encoder.encoder (post-relu)" in names and "encoder.layers_2.mixer.residadd" in names
     by = {r["name"]: r for r in res}
     assert by["inputs"]["abs_error_max"] <= 2.0 ** -15          # FLOOR to 16 bits at exponent 15 (fxprun.py:69-75)
-    for r in res:                                               # w8a16 tracks the float model closely at every stage
-        assert np.isfinite(r["abs_error_mean"]) and r["abs_error_mean"] < 0.02 * r["xhat_absmax"], r
-    assert by["decoder"]["rel_error_med"] < 0.25 and by["encoder.encoder (post-relu)"]["rel_error_med"] < 0.05
+    for r in res:
+        assert all(np.isfinite(r[k]) for k in ("abs_error_mean", "abs_error_max", "rel_error_med", "xhat_absmax")), r
+    # what 16-bit activations and 8-bit weights leave of the float model where nothing else interferes: the encoder and the
+    # LUT sigmoid track it to a percent.  (Deeper stages of this random-init model do not -- the report's job is to show
+    # where: 8-bit B_bar with one shared exponent rounds most of its rows to zero, profiles/r03_verify_report.md.)
+    assert by["encoder.encoder (post-relu)"]["rel_error_med"] < 0.02 and by["encoder.layers_0.mixer.out2_sigmoid"]["rel_error_med"] < 0.05
+    assert by["encoder.layers_1.input"]["abs_error_mean"] == by["encoder.layers_0.mixer.output"]["abs_error_mean"]
     assert (tmp_path / "r1" / "report.md").read_text().count("\n| ") >= 41
     # the same report from the activations file
     assert fxprun.main(common + ["--activations_fname", str(tmp_path / "a.npz"), "--report", str(tmp_path / "r2")]) == 0
