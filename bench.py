@@ -103,7 +103,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
     ap.add_argument("--inflight", type=int, default=3, help="launch sets in flight (streams); 1 = one at a time")
-    ap.add_argument("--groups", type=int, default=8,
+    ap.add_argument("--groups", type=int, default=16,
                     help="reference batches per launch set (s5fxp_forward_opts::groups): G independent batches of --batch sequences, each "
                          "its own compute_best batch, enqueued as one set of kernel launches; a step is still ONE batch")
     ap.add_argument("--no-scan-sweep", action="store_true", help="skip the extra recurrence-kernel measurement at 4x batch")
@@ -189,13 +189,22 @@ def main() -> None:
     G = 1 if (allreduce or sharded) else max(1, min(args.groups, args.steps))
     from sparsernns_amd.engine import InflightRunner
     fxs, ys = [], []
-    for lane in range(depth):
-        if sharded:  # this rank's slice of the one global batch of lane `lane`
+    if sharded:
+        for lane in range(depth):  # this rank's slice of the one global batch of lane `lane`
             x = np.concatenate([synth.make_input(1, L, dims["d_in"], seed=100000 * lane + lo + i, scale=in_scale) for i in range(B)])
-        else:  # every rank / lane / group its own batch
-            x = np.concatenate([synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + lane + 4096 * g, scale=in_scale) for g in range(G)])
-        fxs.append(fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
-                               round_mode=RoundingMode.FLOOR))
+            fxs.append(fxp_from_fp(x, bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True,
+                                   round_mode=RoundingMode.FLOOR))
+    else:
+        # max(G, depth) distinct batches per rank (generating one takes about a second on the host); a lane's launch set is G of
+        # them starting at the lane's own offset, so no two sets in flight are the same tensor and every group of a set differs
+        nb = max(G, depth)
+        pool = [fxp_from_fp(synth.make_input(B, L, dims["d_in"], seed=1000 + 16 * rank + 4096 * j, scale=in_scale),
+                            bits=qc["encoder"]["inp_bits"], exp=qc["encoder"]["inp_exp"], signed=True, round_mode=RoundingMode.FLOOR) for j in range(nb)]
+        for lane in range(depth):
+            data = torch.cat([pool[(lane + g) % nb].data for g in range(G)])
+            fxs.append(FxpArray(data, pool[0].bits, pool[0].exp, True))
+        del pool
+    for lane in range(depth):
         ys.append(torch.empty((G * B, L, dims["d_out"]), dtype=torch.int32, device=dev))
     fx, y = fxs[0], ys[0]
     n_ev = 2 * dims["n_layers"]

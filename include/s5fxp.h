@@ -202,7 +202,9 @@ size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L);
  *       S5FXP_PATH_FUSED (the int8-MFMA tile kernels + the quad / pair recurrence kernels),
  *   [8 + 8*l + 0..4] layer l: exponents chosen by the 4 BatchNorm ops and the residual add,
  *   [8 + 8*l + 5]    layer l: the recurrence kernel that was enqueued first, coded as s5fxp_model_recurrence_kernel
- *                    (5 = the exact 32-bit quad chain of a S5FXP_FWD_EXACT forward). */
+ *                    (5 = the exact 32-bit quad chain of a S5FXP_FWD_EXACT forward),
+ *   [8 + 8*l + 6]    layer l: the state slots its kernels ran on: P, or P / 2 when the layer was compacted to its live
+ *                    states (s5fxp_model_live_states). */
 #define S5FXP_STATUS_WORDS 128
 enum { S5FXP_PATH_GENERIC = 1, S5FXP_PATH_FUSED = 2 };
 enum {
@@ -274,7 +276,8 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
 
 /* Environment (experiments and tests only; read ONCE by s5fxp_model_create and stored in the handle, never by a forward):
  *   S5FXP_NO_PAIR, S5FXP_PAIR_GLOBAL, S5FXP_PAIRL_BLOCKS=16   recurrence kernel choice (see s5fxp_model_recurrence_kernel)
- *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT                             unpacked gate epilogues / four-reduction BatchNorm exponents
+ *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT, S5FXP_NO_COMPACT           unpacked gate epilogues / four-reduction BatchNorm exponents / no
+ *                                                              live-state compaction
  *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward
  * Results do not depend on any of them. */
@@ -290,6 +293,11 @@ int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_t *x, int x
                         int32_t *y_exp_dev, void *workspace, size_t workspace_bytes, int32_t *status,
                         const s5fxp_layer_trace *trace, const s5fxp_forward_opts *opts, void *stream);
 int s5fxp_model_layer_out_bits(const s5fxp_model *m, int layer);
+/* States of `layer` whose rows of B_bar are not all zero.  The others receive Bu = 0 at every step and stay (0, 0) from a
+ * zero carry (fxpmodel.py:147-172), so their columns of C multiply zeros: when at most P / 2 states are live, forwards on
+ * the fused path that neither trace the states nor carry them in or out run the layer's kernels on P / 2 state slots
+ * (bit-identical; S5FXP_NO_COMPACT at model creation switches it off).  -1: bad argument. */
+int s5fxp_model_live_states(const s5fxp_model *m, int layer);
 
 /* Static facts about a created model (for INTEGRATION / debugging). */
 int s5fxp_model_out_exp(const s5fxp_model *m);

@@ -111,6 +111,7 @@ def _load():
         "s5fxp_model_forward": (i, [p, p, i, i, i, i, p, p, C.c_size_t, p, C.POINTER(LayerTrace), C.POINTER(ForwardOpts), p]),
         "s5fxp_layer_forward": (i, [p, i, p, i, i, i, i, p, p, p, C.c_size_t, p, C.POINTER(LayerTrace), C.POINTER(ForwardOpts), p]),
         "s5fxp_model_layer_out_bits": (i, [p, i]),
+        "s5fxp_model_live_states": (i, [p, i]),
         "s5fxp_model_out_exp": (i, [p]),
         "s5fxp_model_out_bits": (i, [p]),
         "s5fxp_model_is_fast": (i, [p]),
@@ -126,7 +127,7 @@ def _load():
 lib = _load()
 EXPORTED_SYMBOLS = ("s5fxp_version s5fxp_strerror s5fxp_from_fp s5fxp_to_float s5fxp_change_cfg s5fxp_dense s5fxp_dense_csr s5fxp_add "
                     "s5fxp_mul s5fxp_add_cb s5fxp_mul_cb s5fxp_relu s5fxp_sigmoid s5fxp_scan s5fxp_assoc_scan_c64 s5fxp_model_blob_bytes "
-                    "s5fxp_model_create s5fxp_model_destroy s5fxp_workspace_bytes s5fxp_model_forward s5fxp_layer_forward s5fxp_model_layer_out_bits "
+                    "s5fxp_model_create s5fxp_model_destroy s5fxp_workspace_bytes s5fxp_model_forward s5fxp_layer_forward s5fxp_model_layer_out_bits s5fxp_model_live_states "
                     "s5fxp_model_out_exp s5fxp_model_out_bits s5fxp_model_is_fast s5fxp_model_recurrence_kernel s5fxp_model_recurrence_xmax").split()
 
 

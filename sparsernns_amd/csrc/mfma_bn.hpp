@@ -18,10 +18,12 @@
 namespace s5 {
 
 // one launch instead of two memsets at the head of a forward: the status words and the per-layer device state.  What the
-// host knows before the forward goes into the status words here: [2] the path, [8 + 8l + 5] layer l's recurrence kernel.
+// host knows before the forward goes into the status words here: [2] the path, [8 + 8l + 5] layer l's recurrence kernel,
+// [8 + 8l + 6] the state slots its kernels run on (P, or P / 2 for a layer compacted to its live states).
 struct StatusInit {
     int32_t path;
-    int32_t rk[15]; // 8 + 8 * n_layers <= S5FXP_STATUS_WORDS
+    int32_t rk[15];    // 8 + 8 * n_layers <= S5FXP_STATUS_WORDS
+    int32_t slots[15];
 };
 __global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb, StatusInit si, int n_layers, GroupOff go)
 {
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, 
             int32_t v = 0;
             if (i == 2) v = si.path;
             else if (i >= 8 && (i & 7) == 5 && (i - 8) / 8 < n_layers) v = si.rk[(i - 8) / 8];
+            else if (i >= 8 && (i & 7) == 6 && (i - 8) / 8 < n_layers) v = si.slots[(i - 8) / 8];
             a[i] = v;
         } else b[i - na] = 0;
     }

@@ -69,7 +69,10 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
 // the shift to the state exponent <= 16; one item is then 8 bytes); 2: the pair kernel's K stream (scan_quad.hpp):
 // K = (Bu << 16) + k in pair-native order, one 16-byte item per producer lane; 3: the LDS-fed pair kernel's int16 Bu
 // stream (pair16-native), one 8-byte item per producer lane
-template <int KS, int NT, bool TRACE, int SM = 0>
+// NC: 32-column tiles of [B_re | B_im] (= 2P / 32).  NC == NT: one tile per wave, both 32-frame halves of the tile's 64
+// frames; NC == NT / 2 (a layer compacted to its live states, s5fxp_fast.hpp): wave w takes column tile w % NC and the ONE
+// half w / NC -- the workgroup keeps its size, so phase A (the bulk of the kernel) is unchanged.
+template <int KS, int NT, bool TRACE, int SM = 0, int NC = NT>
 __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff go)
 {
     {
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         gshift(a.bn.dyn, g * go.ws); gshift(a.bn.xe.dyn, g * go.ws); gshift(a.x, g * go.ws); gshift(a.bq, g * go.ws); gshift(a.u, g * go.ws);
         gshift(a.ext, g * go.ws); gshift(a.status, g * go.status); gshift(a.status_exps, g * go.status);
     }
-    constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NT;
+    static_assert(NC == NT || 2 * NC == NT, "column tiles per workgroup");
+    constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NC, SUB0_STEP = NT / NC; // halves a wave takes: 2 / SUB0_STEP
     constexpr int VPF = H / 8;             // 16-byte vectors per frame
     constexpr int NTHR = 64 * NT;          // one wave per column tile: 256 threads at dim 0.5, 512 at dim 1.0
     constexpr int NV = FT * VPF / NTHR;    // vectors per thread and tile
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
     int32_t *tab = reinterpret_cast<int32_t *>(smem);             // 4*H BatchNorm operands
     int8_t *Xh = smem + 16 * H, *Xl = Xh + 2 * PLANE;             // [buf][frame][KP]
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
+    const int wct = wave % NC, wsub = wave / NC; // this wave's column tile and first 32-frame half
     const StepRange sr{a.t_lo, a.t_len};
     const int64_t tiles = (a.N / a.L) * ((sr.t_len + FT - 1) / FT);
     int64_t tile = blockIdx.x;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
     int32_t csv[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int col = 32 * (wave + NT * c) + r;
+        const int col = 32 * (wct + NC * c) + r;
         csv[c] = a.w.cs128[col];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -165,14 +170,15 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         // ---- phase B: this wave's column tile(s), both 32-frame halves
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
-            const int col = 32 * (wave + NT * c) + r;
+            const int col = 32 * (wct + NC * c) + r;
             // SM >= 2: the weight columns are packed so that lanes r and r ^ 16 hold re and im of the SAME state
             // (pack_fast: bproj_pair); otherwise columns [0, P) are re, [P, 2P) im
-            const int cc = SM >= 2 ? (r >> 4) : (col >= PC ? 1 : 0), p = SM >= 2 ? 16 * (wave + NT * c) + (r & 15) : col - cc * PC;
+            const int cc = SM >= 2 ? (r >> 4) : (col >= PC ? 1 : 0), p = SM >= 2 ? 16 * (wct + NC * c) + (r & 15) : col - cc * PC;
             const int rs = cc ? a.rs_im : a.rs_re, bits = cc ? a.bim_bits : a.bre_bits, sh = cc ? a.sh_im : a.sh_re;
             const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+            for (int sub0 = 0; sub0 < 2; sub0 += SUB0_STEP) {
+                const int sub = sub0 + wsub;
                 const int8_t *rowh = xh + (32 * sub + r) * KP + 16 * h, *rowl = xl + (32 * sub + r) * KP + 16 * h;
                 v16i acc;
 #pragma unroll

@@ -313,6 +313,7 @@ struct ModelCfg {
     bool no_pair = false;     // S5FXP_NO_PAIR: never the pair recurrence kernel
     bool pair_global = false; // S5FXP_PAIR_GLOBAL: pair kernel fed from an int32 K stream in global memory (no helper wave)
     bool no_pk16 = false;     // S5FXP_NO_PK16: unpacked epilogues in the gate kernel
+    bool no_compact = false;  // S5FXP_NO_COMPACT: never run a layer on its live states only (s5fxp_fast.hpp FastLayer)
     int pairl_blocks = 32;    // S5FXP_PAIRL_BLOCKS=16: 16 time blocks per LDS buffer of the LDS-fed pair kernel
     int64_t cap_enc = 512, cap_dec = 512, cap_cgate = 512, cap_bproj = 1024, cap_resid = 512; // S5FXP_WGS_*: workgroups per launch
     static ModelCfg from_env()
@@ -325,7 +326,7 @@ struct ModelCfg {
             return (int64_t)(v > 0 ? v : dflt);
         };
         c.debug_sync = on("S5FXP_DEBUG_SYNC"); c.no_bn_ext = on("S5FXP_NO_BN_EXT"); c.no_pair = on("S5FXP_NO_PAIR");
-        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16");
+        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT");
         { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); c.pairl_blocks = e && std::atoi(e) == 16 ? 16 : 32; }
         c.cap_enc = cap("S5FXP_WGS_ENC", c.cap_enc); c.cap_dec = cap("S5FXP_WGS_DEC", c.cap_dec);
         c.cap_cgate = cap("S5FXP_WGS_CGATE", c.cap_cgate); c.cap_bproj = cap("S5FXP_WGS_BPROJ", c.cap_bproj);
@@ -371,6 +372,50 @@ void pack_dense(Packer &p, const s5fxp_dense_desc &d, DenseDev &o, bool allow24)
     o.x24 = allow24 && fits24(d.weight, (size_t)d.K * d.M);
 }
 
+// Exactness bounds of the fast recurrence kernels (scan_quad.hpp) over the states idx[0..n) of a layer that runs on P_slots
+// state slots (all P states, or the live ones of a compacted layer: a dead state's coefficients never meet a non-zero state).
+struct ScanBounds {
+    bool quad_ok = false, pair_ok = false;
+    int32_t quad_xmax = 0, pair_xmax = 0;
+};
+ScanBounds scan_bounds(const s5fxp_ssm_desc &ssm, const int *idx, int n, int P_slots, bool allow24)
+{
+    ScanBounds o;
+    // scaled coefficients c = A * 2^(16-e) must fit 24 signed bits; |c*x| + 2^16 < 2^31 bounds the state
+    const int sre = 16 - ssm.A_re_exp, sim = 16 - ssm.A_im_exp;
+    int64_t cmax = 1;
+    for (int j = 0; j < n; ++j) {
+        const int q = idx[j];
+        const int64_t ar = std::llabs((long long)ssm.A_re[q]), ai = std::llabs((long long)ssm.A_im[q]);
+        const int smax = sre > sim ? sre : sim;
+        if (smax >= 0 && smax < 24) {
+            cmax = std::max(cmax, ar << smax);
+            cmax = std::max(cmax, ai << smax);
+        }
+    }
+    o.quad_ok = allow24 && (P_slots % 16 == 0) && sre >= 0 && sim >= 0 && sre < 16 && sim < 16 && cmax < (1 << 23);
+    o.quad_xmax = (int32_t)std::min<int64_t>(((int64_t(1) << 31) - 1 - 65536) / cmax, (1 << 23) - 1);
+    // pair kernel: Bu is folded into the addend of the own product (always an Ai product), so
+    //   |Ai| * 2^(16-e) * |x| + 2^16 * (bmax + 1) <= 2^31 - 1   and   |Ar| * 2^(16-e) * |x| <= 2^31 - 1
+    // with bmax = the largest |Bu| after the shift to the state exponent (static: its bits minus the shift)
+    const int sh_re = ssm.Bu_re_exp - ssm.x_re_exp, sh_im = ssm.Bu_im_exp - ssm.x_im_exp;
+    const int bb_re = ssm.Bu_re_bits - sh_re, bb_im = ssm.Bu_im_bits - sh_im; // bits of the shifted Bu
+    if (o.quad_ok && P_slots % 32 == 0 && bb_re >= 1 && bb_re <= 16 && bb_im >= 1 && bb_im <= 16) {
+        const int64_t lim = (int64_t(1) << 31) - 1;
+        int64_t xm = 32766;
+        for (int j = 0; j < n; ++j) {
+            const int q = idx[j];
+            const int64_t ar = std::llabs((long long)ssm.A_re[q]), ai = std::llabs((long long)ssm.A_im[q]);
+            const int64_t room_re = lim - 65536 * ((int64_t(1) << (bb_re - 1)) + 1), room_im = lim - 65536 * ((int64_t(1) << (bb_im - 1)) + 1);
+            if (ai) xm = std::min({xm, room_re / (ai << sre), room_im / (ai << sim)});
+            if (ar) xm = std::min({xm, lim / (ar << sre), lim / (ar << sim)});
+        }
+        o.pair_xmax = (int32_t)xm;
+        o.pair_ok = xm >= 16384; // below that the quad kernel (bound 32767) is the better optimistic choice
+    }
+    return o;
+}
+
 void pack_layer(Packer &p, const s5fxp_layer_desc &l, LayerDev &o, bool allow24)
 {
     const int H = l.ssm.H, P = l.ssm.P;
@@ -401,37 +446,10 @@ void pack_layer(Packer &p, const s5fxp_layer_desc &l, LayerDev &o, bool allow24)
     o.c24 = allow24 && fits24(t2.data(), t2.size()) && fits24(t3.data(), t3.size());
     o.D = p.put(l.ssm.D, H);
     {
-        // scaled coefficients c = A * 2^(16-e) must fit 24 signed bits; |c*x| + 2^16 < 2^31 bounds the state
-        const int sre = 16 - l.ssm.A_re_exp, sim = 16 - l.ssm.A_im_exp;
-        int64_t cmax = 1;
-        for (int q = 0; q < P; ++q) {
-            const int64_t ar = std::llabs((long long)l.ssm.A_re[q]), ai = std::llabs((long long)l.ssm.A_im[q]);
-            const int smax = sre > sim ? sre : sim;
-            if (smax >= 0 && smax < 24) {
-                cmax = std::max(cmax, ar << smax);
-                cmax = std::max(cmax, ai << smax);
-            }
-        }
-        o.quad_ok = allow24 && (P % 16 == 0) && sre >= 0 && sim >= 0 && sre < 16 && sim < 16 && cmax < (1 << 23);
-        o.quad_xmax = (int32_t)std::min<int64_t>(((int64_t(1) << 31) - 1 - 65536) / cmax, (1 << 23) - 1);
-        // pair kernel: Bu is folded into the addend of the own product (always an Ai product), so
-        //   |Ai| * 2^(16-e) * |x| + 2^16 * (bmax + 1) <= 2^31 - 1   and   |Ar| * 2^(16-e) * |x| <= 2^31 - 1
-        // with bmax = the largest |Bu| after the shift to the state exponent (static: its bits minus the shift)
-        const int sh_re = l.ssm.Bu_re_exp - l.ssm.x_re_exp, sh_im = l.ssm.Bu_im_exp - l.ssm.x_im_exp;
-        const int bb_re = l.ssm.Bu_re_bits - sh_re, bb_im = l.ssm.Bu_im_bits - sh_im; // bits of the shifted Bu
-        o.pair_ok = false;
-        if (o.quad_ok && P % 32 == 0 && bb_re >= 1 && bb_re <= 16 && bb_im >= 1 && bb_im <= 16) {
-            const int64_t lim = (int64_t(1) << 31) - 1;
-            int64_t xm = 32766;
-            for (int q = 0; q < P; ++q) {
-                const int64_t ar = std::llabs((long long)l.ssm.A_re[q]), ai = std::llabs((long long)l.ssm.A_im[q]);
-                const int64_t room_re = lim - 65536 * ((int64_t(1) << (bb_re - 1)) + 1), room_im = lim - 65536 * ((int64_t(1) << (bb_im - 1)) + 1);
-                if (ai) xm = std::min({xm, room_re / (ai << sre), room_im / (ai << sim)});
-                if (ar) xm = std::min({xm, lim / (ar << sre), lim / (ar << sim)});
-            }
-            o.pair_xmax = (int32_t)xm;
-            o.pair_ok = xm >= 16384; // below that the quad kernel (bound 32767) is the better optimistic choice
-        }
+        std::vector<int> all(P);
+        for (int q = 0; q < P; ++q) all[q] = q;
+        const ScanBounds sb = scan_bounds(l.ssm, all.data(), P, P, allow24);
+        o.quad_ok = sb.quad_ok; o.quad_xmax = sb.quad_xmax; o.pair_ok = sb.pair_ok; o.pair_xmax = sb.pair_xmax;
     }
     pack_dense(p, l.out2, o.out2, allow24);
     o.l_bits = l.l_bits; o.l_exp = l.l_exp; o.r_bits = l.r_bits; o.r_exp = l.r_exp; o.res_bits = l.res_bits;
@@ -559,9 +577,13 @@ extern "C" int s5fxp_model_recurrence_xmax(const s5fxp_model *m, int layer)
     const int k = s5fxp_model_recurrence_kernel(m, layer);
     if (k < 0) return -1;
     const LayerDev &l = m->layers[layer];
-    if (k >= 3) return l.pair_xmax;
-    if (k == 2) return l.quad_xmax < 32766 ? l.quad_xmax : 32766;
-    return l.quad_ok ? l.quad_xmax : 0;
+    // a plain forward (no traces, no carry) of a compactable layer runs on its live states: their bounds apply
+    const bool compact = m->fast && m->fast->layers[layer].compact_ok && !m->cfg.no_compact;
+    const int32_t pair_xmax = compact ? m->fast->layers[layer].c_bounds.pair_xmax : l.pair_xmax;
+    const int32_t quad_xmax = compact ? m->fast->layers[layer].c_bounds.quad_xmax : l.quad_xmax;
+    if (k >= 3) return pair_xmax;
+    if (k == 2) return quad_xmax < 32766 ? quad_xmax : 32766;
+    return l.quad_ok ? quad_xmax : 0;
 }
 
 extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
@@ -570,7 +592,7 @@ extern "C" int s5fxp_model_recurrence_kernel(const s5fxp_model *m, int layer)
     const LayerDev &l = m->layers[layer];
     if (!m->fast) return l.quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
     // the fused path: the same decision forward_fast takes (and reports in status word [8 + 8*layer + 5])
-    const int code = select_rung(m, layer, S5FXP_FWD_DEFER_REDO, false).code;
+    const int code = select_rung(m, layer, S5FXP_FWD_DEFER_REDO, false, m->fast->layers[layer].compact_ok && !m->cfg.no_compact).code;
     return code == RK_EXACT ? 1 : code; // no fast rung applies: a quad kernel all the same, the 32-bit chain
 }
 
@@ -835,8 +857,10 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
     {
         StatusInit si{};
         si.path = S5FXP_PATH_GENERIC;
-        for (int li = 0; li < m->n_layers; ++li)
+        for (int li = 0; li < m->n_layers; ++li) {
             si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+            si.slots[li] = m->P;
+        }
         hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
     }
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)(m->n_layers ? m->n_layers : 1), st)))) return rc;
@@ -898,6 +922,7 @@ extern "C" int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_
         StatusInit si{};
         si.path = S5FXP_PATH_GENERIC;
         si.rk[layer] = m->layers[layer].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
+        si.slots[layer] = m->P;
         hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
     }
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)m->n_layers, st)))) return rc;
@@ -914,6 +939,12 @@ extern "C" int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_
     if ((rc = generic_layers(g, layer, layer + 1, h, hn, hb, he))) return rc;
     if (y_exp_dev && (rc = hip_rc(hipMemcpyAsync(y_exp_dev, he.dyn, sizeof(int32_t), hipMemcpyDeviceToDevice, st)))) return rc;
     return launch_rc();
+}
+extern "C" int s5fxp_model_live_states(const s5fxp_model *m, int layer)
+{
+    if (!m || layer < 0 || layer >= m->n_layers) return -1;
+    if (m->fast) return m->fast->layers[layer].n_live;
+    return m->P;
 }
 extern "C" int s5fxp_model_layer_out_bits(const s5fxp_model *m, int layer)
 {

@@ -17,6 +17,19 @@ struct FastLayer {
     const int16_t *sigdir = nullptr; // [1 << sigdir_bits] when the sigmoid input has <= 12 bits (DIRECT)
     int sigdir_bits = 0;
     bool bias16 = false; // every out2 bias, moved to out_exp, fits 16 bits (a condition of the gate kernel's PK16 epilogues)
+    // Live-state compaction.  A state whose rows of B_bar_re and B_bar_im are all zero (8-bit B_bar with ONE exponent per matrix
+    // rounds the rows of slow states away: 43-46 of 64 on the N-DNS recipe at dim_scale 0.5, profiles/r03_sparsity_census.log)
+    // receives Bu = 0 at every step, so from a zero carry it stays (0, 0) for ever: asr(A * 0) = 0, the complex ReLU keeps
+    // (0, 0), and its column of C multiplies zeros (fxpmodel.py:147-172, :740-763).  When at most half of a layer's states
+    // are live, the layer is ALSO packed over P / 2 state slots -- the live states in their order, then zero slots -- and
+    // forwards that neither trace the states nor carry them in or out run every kernel of the layer on that half: half the
+    // bytes of both recurrence streams, half the recurrence waves, half the gate kernel's phase A.  Bit-identical by the
+    // argument above (the dropped terms are exact zeros of int32 sums).
+    bool compact_ok = false;
+    int n_live = 0;
+    MfmaWDev c_bproj, c_bproj_pair, c_cre, c_cim;
+    ScanBounds c_bounds; // the recurrence kernels' exactness bounds over the live states only
+    const int32_t *c_a_re = nullptr, *c_a_im = nullptr; // (P / 2) Lambda_bar of the slots (0 for the empty ones)
 };
 
 struct FastModel {
@@ -132,6 +145,38 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
             const int32_t v = fxp::chexp(l.out2.bias[ch], l.out2.b_bits, l.out2.b_exp, l.out2.out_exp);
             o.bias16 = o.bias16 && v >= -32768 && v <= 32767;
         }
+        {
+            std::vector<int> idx;
+            for (int q = 0; q < P; ++q) {
+                bool live = false;
+                for (int k = 0; k < H && !live; ++k) live = s.B_re[(size_t)q * H + k] != 0 || s.B_im[(size_t)q * H + k] != 0;
+                if (live) idx.push_back(q);
+            }
+            o.n_live = (int)idx.size();
+            const int Pc = P / 2;
+            o.compact_ok = Pc % 32 == 0 && o.n_live <= Pc;
+            if (o.compact_ok) {
+                o.c_bounds = scan_bounds(s, idx.data(), o.n_live, Pc, true);
+                idx.resize(Pc, -1);
+                auto bre = [&](int st, int k) { return idx[st] < 0 ? 0 : s.B_re[(size_t)idx[st] * H + k]; };
+                auto bim = [&](int st, int k) { return idx[st] < 0 ? 0 : s.B_im[(size_t)idx[st] * H + k]; };
+                pack_mfma(p, [&](int k, int ch) { return ch < Pc ? bre(ch, k) : bim(ch - Pc, k); }, H, 2 * Pc, o.c_bproj);
+                pack_mfma(p, [&](int k, int ch) {
+                              const int st = 16 * (ch / 32) + (ch & 15);
+                              return (ch & 16) ? bim(st, k) : bre(st, k);
+                          }, H, 2 * Pc, o.c_bproj_pair);
+                pack_mfma(p, [&](int k, int ch) { return idx[k] < 0 ? 0 : s.C_re[(size_t)ch * P + idx[k]]; }, Pc, H, o.c_cre);
+                pack_mfma(p, [&](int k, int ch) { return idx[k] < 0 ? 0 : s.C_im[(size_t)ch * P + idx[k]]; }, Pc, H, o.c_cim);
+                std::vector<int32_t> ar(Pc, 0), ai(Pc, 0);
+                for (int st = 0; st < Pc; ++st)
+                    if (idx[st] >= 0) {
+                        ar[st] = s.A_re[idx[st]];
+                        ai[st] = s.A_im[idx[st]];
+                    }
+                o.c_a_re = reinterpret_cast<const int32_t *>(put_raw(p, ar.data(), ar.size() * 4));
+                o.c_a_im = reinterpret_cast<const int32_t *>(put_raw(p, ai.data(), ai.size() * 4));
+            }
+        }
         std::vector<int32_t> Dp(o.cre.w.Np, 0);
         for (int h = 0; h < H; ++h) Dp[h] = s.D[h];
         o.Dpad = reinterpret_cast<const int32_t *>(put_raw(p, Dp.data(), Dp.size() * 4));
@@ -219,14 +264,16 @@ struct Rung {
     bool exact, defer, quad, s16, pair, pairl;
     int code;
 };
-Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced)
+Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced, bool compact)
 {
     const LayerDev &l = m->layers[li];
+    const bool quad_ok = compact ? m->fast->layers[li].c_bounds.quad_ok : l.quad_ok;
+    const bool pair_ok = compact ? m->fast->layers[li].c_bounds.pair_ok : l.pair_ok;
     const s5fxp_ssm_desc &s = l.sd;
     Rung r{};
     r.exact = (fwd_flags & S5FXP_FWD_EXACT) != 0;
     r.defer = (fwd_flags & S5FXP_FWD_DEFER_REDO) && !r.exact;
-    r.quad = l.quad_ok && !r.exact;
+    r.quad = quad_ok && !r.exact;
     const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
     // optimistic forwards (the caller repeats with S5FXP_FWD_EXACT if the range check fires) keep both recurrence
     // streams as int16 when every Bu value, shifted to the state exponent, provably fits: half the bytes of the
@@ -235,7 +282,7 @@ Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced)
     // ... and, where the layer's coefficients leave room for Bu in the multiply's addend, the pair kernel (two lanes
     // per state, four instructions per step), fed either from an int16 Bu stream through LDS by a helper wave (default:
     // the HBM bytes of the quad16 path) or from an int32 K stream in global memory (ModelCfg::pair_global)
-    r.pair = r.s16 && l.pair_ok && !m->cfg.no_pair && !(fwd_flags & S5FXP_FWD_NO_PAIR);
+    r.pair = r.s16 && pair_ok && !m->cfg.no_pair && !(fwd_flags & S5FXP_FWD_NO_PAIR);
     r.pairl = r.pair && !m->cfg.pair_global;
     r.code = r.pairl ? RK_PAIRL : r.pair ? RK_PAIR : r.quad ? (r.s16 ? RK_QUAD16 : RK_QUAD32) : RK_EXACT;
     return r;
@@ -303,7 +350,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     // kernel each layer gets ([8 + 8l + 5])
     StatusInit si{};
     si.path = S5FXP_PATH_FUSED;
-    for (int li = 0; li < m->n_layers; ++li) si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr).code;
+    for (int li = 0; li < m->n_layers; ++li) {
+        const bool compact = F.layers[li].compact_ok && !cfg.no_compact && !traces && !state_in && !state_out;
+        si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr, compact).code;
+        si.slots[li] = compact ? m->P / 2 : m->P;
+    }
     hipLaunchKernelGGL(k_clear2, dim3(8, G), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
                        (int)(w.dyn_bytes / 4), si, m->n_layers, go);
     const bool bn_ext = fast_bn_ext(m);
@@ -426,11 +477,18 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
         // ---- B projection -> scan-native stream (+ u for the C projection)
         const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
-        const Rung rung = select_rung(m, li, fwd_flags, tr != nullptr);
+        // live-state compaction (FastLayer): this layer's kernels run on P / 2 state slots
+        const bool compact = fl.compact_ok && !cfg.no_compact && !tr && !state_in && !state_out;
+        const Rung rung = select_rung(m, li, fwd_flags, tr != nullptr, compact);
         const bool quad = rung.quad, s16 = rung.s16, pair = rung.pair, pairl = rung.pairl;
+        const int32_t l_pair_xmax = compact ? fl.c_bounds.pair_xmax : l.pair_xmax, l_quad_xmax = compact ? fl.c_bounds.quad_xmax : l.quad_xmax;
+        const int P = compact ? m->P / 2 : m->P;
+        const int32_t *la_re = compact ? fl.c_a_re : l.a_re, *la_im = compact ? fl.c_a_im : l.a_im;
+        const MfmaW &w_bproj = compact ? fl.c_bproj.w : fl.bproj.w, &w_bproj_pair = compact ? fl.c_bproj_pair.w : fl.bproj_pair.w;
+        const MfmaW &w_cre = compact ? fl.c_cre.w : fl.cre.w, &w_cim = compact ? fl.c_cim.w : fl.cim.w;
         {
             BprojM2Args a{};
-            a.bn = bn; a.x = h; a.w = fl.bproj.w; a.bq = I32(w.bq); a.u = I16(w.u);
+            a.bn = bn; a.x = h; a.w = w_bproj; a.bq = I32(w.bq); a.u = I16(w.u);
             a.tr_bu_re = tr ? tr->Bu_re : nullptr; a.tr_bu_im = tr ? tr->Bu_im : nullptr;
             a.tr_pre_s5 = tr ? tr->pre_s5 : nullptr; a.tr_u = tr ? tr->u : nullptr;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H; a.P = P;
@@ -448,23 +506,30 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? cap_bproj / 2 : cap_bproj, per = (tl + cap - 1) / cap;
                 const unsigned bthr = big ? 512 : 256; // one wave per 32-column tile of [B_re | B_im]
                 const unsigned pgrid = (unsigned)((tl + per - 1) / per);
+                // SM: the stream the recurrence rung wants (proj_p.hpp); a compacted layer has half the column tiles
+                auto bproj = [&](auto sm) {
+                    constexpr int SM = decltype(sm)::value;
+                    if (big) {
+                        if (compact) launch_smem(k_bproj_p<6, 8, false, SM, 4>, pgrid, smem, st, a, bthr, G, go);
+                        else launch_smem(k_bproj_p<6, 8, false, SM, 8>, pgrid, smem, st, a, bthr, G, go);
+                    } else {
+                        if (compact) launch_smem(k_bproj_p<3, 4, false, SM, 2>, pgrid, smem, st, a, bthr, G, go);
+                        else launch_smem(k_bproj_p<3, 4, false, SM, 4>, pgrid, smem, st, a, bthr, G, go);
+                    }
+                };
                 if (tr) {
                     if (big) launch_smem(k_bproj_p<6, 8, true>, pgrid, smem, st, a, bthr, G, go);
                     else launch_smem(k_bproj_p<3, 4, true>, pgrid, smem, st, a, bthr, G, go);
                 } else if (pairl) {
-                    a.w = fl.bproj_pair.w;
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 3>, pgrid, smem, st, a, bthr, G, go);
-                    else launch_smem(k_bproj_p<3, 4, false, 3>, pgrid, smem, st, a, bthr, G, go);
+                    a.w = w_bproj_pair;
+                    bproj(std::integral_constant<int, 3>{});
                 } else if (pair) {
-                    a.w = fl.bproj_pair.w;
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 2>, pgrid, smem, st, a, bthr, G, go);
-                    else launch_smem(k_bproj_p<3, 4, false, 2>, pgrid, smem, st, a, bthr, G, go);
+                    a.w = w_bproj_pair;
+                    bproj(std::integral_constant<int, 2>{});
                 } else if (s16) {
-                    if (big) launch_smem(k_bproj_p<6, 8, false, 1>, pgrid, smem, st, a, bthr, G, go);
-                    else launch_smem(k_bproj_p<3, 4, false, 1>, pgrid, smem, st, a, bthr, G, go);
+                    bproj(std::integral_constant<int, 1>{});
                 } else {
-                    if (big) launch_smem(k_bproj_p<6, 8, false>, pgrid, smem, st, a, bthr, G, go);
-                    else launch_smem(k_bproj_p<3, 4, false>, pgrid, smem, st, a, bthr, G, go);
+                    bproj(std::integral_constant<int, 0>{});
                 }
             }
         }
@@ -484,7 +549,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         };
         if (pairl) {
             ScanPairLArgs q{};
-            q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
             // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
@@ -498,27 +563,27 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             };
             if (blocks == 16) launch_pairl(k_scan_pairl_asm<16>, 3 * 16 * 1024);
             else launch_pairl(k_scan_pairl_asm<32>, 3 * 32 * 1024);
-            xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax;
+            xmax = l_pair_xmax < xmax ? l_pair_xmax : xmax;
         } else if (pair) {
             ScanPairArgs q{};
-            q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.k = I32(w.bq); q.xs = I16(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             launch_scan(k_scan_pair_asm, dim3((unsigned)((int64_t)B * (P / 32))), dim3(64), q);
-            xmax = l.pair_xmax < xmax ? l.pair_xmax : xmax; // <= 32766: a saturated int16 state fails the check
+            xmax = l_pair_xmax < xmax ? l_pair_xmax : xmax; // <= 32766: a saturated int16 state fails the check
         } else if (quad) {
             ScanQuadArgs q{};
-            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
             {
                 if (s16) launch_scan(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
                 else launch_scan(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
             }
-            xmax = l.quad_xmax < xmax ? l.quad_xmax : xmax;
+            xmax = l_quad_xmax < xmax ? l_quad_xmax : xmax;
             if (s16 && xmax > 32766) xmax = 32766; // a saturated int16 state must fail the check
         } else {
             // states of any width: the exact 32-bit chain in the same quad layout
             ScanQuadArgs q{};
-            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+            q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
             q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = nullptr; q.x0_re = x0_re; q.x0_im = x0_im;
             launch_scan(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
         }
@@ -543,7 +608,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         }
         {
             CGateArgs a{};
-            a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = fl.cre.w; a.w_im = fl.cim.w; a.w_o2 = fl.out2.w;
+            a.u = I16(w.u); a.skip = h; a.xs = I32(w.xs); a.w_re = w_cre; a.w_im = w_cim; a.w_o2 = fl.out2.w;
             a.D = fl.Dpad; a.bias_eff = fl.out2.bias_eff; a.z = I16(w.z); a.sigtab = fl.sigtab; a.sigdir = fl.sigdir; a.sigdir_bits = fl.sigdir_bits; a.mx_slot = 8;
             a.tr_ys = tr ? tr->ys : nullptr; a.tr_out2 = ga.tr_out2; a.tr_sig = ga.tr_sig; a.tr_z = ga.tr_z;
             a.N = N; a.L = L; a.TB = w.TB; a.H = H;
@@ -572,31 +637,30 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     a.t_lo = 0; a.t_len = L;
                     const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + cap_cgate - 1) / cap_cgate;
                     const unsigned cg = (unsigned)((tl + per - 1) / per);
+                    // <S16, DIRECT, PAIR, PK16> of mfma_fused.hpp; KS = state slots / 32 (halved for a compacted layer)
+                    auto cgate = [&](auto s16_t, auto direct_t, auto pair_t, auto pk16_t) {
+                        constexpr bool S16_ = decltype(s16_t)::value, DIR_ = decltype(direct_t)::value, PAIR_ = decltype(pair_t)::value,
+                                       PK_ = decltype(pk16_t)::value;
+                        if (big) {
+                            if (compact) launch6g(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            else launch6g(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                        } else {
+                            if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
+                            else launch6g(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
+                        }
+                    };
+                    using T_ = std::true_type;
+                    using F_ = std::false_type;
                     if (tr) {
                         if (big) launch6g(k_cgate_p<4, 6, true>, cg, smem, a, 768);
                         else launch6g(k_cgate_p<2, 3, true>, cg, smem, a);
-                    } else if (pk16 && pair) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, true, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, true, true>, cg, smem, a);
-                    } else if (pk16) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, false, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, false, true>, cg, smem, a);
-                    } else if (direct && pair) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true, true, 64, false, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true, true, 64, false, true>, cg, smem, a);
-                    } else if (pair) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true, false, 64, false, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true, false, 64, false, true>, cg, smem, a);
-                    } else if (direct) { // (32-frame tiles with three-wave workgroups were tried: 39 vs 36 us)
-                        if (big) launch6g(k_cgate_p<4, 6, false, true, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true, true>, cg, smem, a);
-                    } else if (s16) {
-                        if (big) launch6g(k_cgate_p<4, 6, false, true>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false, true>, cg, smem, a);
-                    } else {
-                        if (big) launch6g(k_cgate_p<4, 6, false>, cg, smem, a, 768);
-                        else launch6g(k_cgate_p<2, 3, false>, cg, smem, a);
-                    }
+                    } else if (pk16 && pair) cgate(T_{}, T_{}, T_{}, T_{});
+                    else if (pk16) cgate(T_{}, T_{}, F_{}, T_{});
+                    else if (direct && pair) cgate(T_{}, T_{}, T_{}, F_{});
+                    else if (pair) cgate(T_{}, F_{}, T_{}, F_{});
+                    else if (direct) cgate(T_{}, T_{}, F_{}, F_{}); // (32-frame tiles with three-wave workgroups were tried: 39 vs 36 us)
+                    else if (s16) cgate(T_{}, F_{}, F_{}, F_{});
+                    else cgate(F_{}, F_{}, F_{}, F_{});
                 }
             }
             // ---- exact re-run, only if a state left the fast kernels' range (LayerDyn::redo); with
@@ -604,7 +668,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             if (!defer) {
                 if (quad) {
                     ScanQuadArgs q{};
-                    q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = l.a_re; q.a_im = l.a_im; q.B = B; q.TB = w.TB; q.P = P;
+                    q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
                     q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.run_if = &d->redo; q.x0_re = x0_re; q.x0_im = x0_im;
                     hipLaunchKernelGGL(k_scan_quad32_asm, dim3((unsigned)((int64_t)B * P / 16), G), dim3(64), 0, st, q, go);
                 }
@@ -619,8 +683,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 if (tr) {
                     if (big) launch6g(k_cgate_p<4, 6, true, false, false, 64, true>, cgw, smem_w, e, 768);
                     else launch6g(k_cgate_p<2, 3, true, false, false, 64, true>, cgw, smem_w, e);
+                } else if (big) {
+                    if (compact) launch6g(k_cgate_p<2, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
+                    else launch6g(k_cgate_p<4, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
                 } else {
-                    if (big) launch6g(k_cgate_p<4, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
+                    if (compact) launch6g(k_cgate_p<1, 3, false, false, false, 64, true>, cgw, smem_w, e);
                     else launch6g(k_cgate_p<2, 3, false, false, false, 64, true>, cgw, smem_w, e);
                 }
             }

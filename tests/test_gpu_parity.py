@@ -979,6 +979,56 @@ def test_streaming_chunks_carry_the_state_like_the_oracle(engine_flags):
         eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), torch.zeros((1, 2, B, dims["P"]), dtype=torch.int32, device="cuda"))
 
 
+@pytest.mark.parametrize("ds", [0.5, 1.0])
+def test_layers_run_on_their_live_states_only(ds, monkeypatch):
+    """A state whose rows of the 8-bit B_bar are all zero never leaves (0, 0) (include/s5fxp.h s5fxp_model_live_states): when at
+    most half of a layer's states are live the fused kernels run the layer on P / 2 state slots.  The status words must say
+    so, the output must be the oracle's on every rung, an engine created with S5FXP_NO_COMPACT must give the same bits on
+    all P slots, and a forward that carries the states in or out must not compact."""
+    import torch
+    from sparsernns_amd import _lib
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=ds, calib_L=256, state_headroom_bits=1))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    eng = model.engine()
+    P, nl = dims["P"], dims["n_layers"]
+    ex = model.export()["params"]["encoder"]
+    live = [int(((np.asarray(ex[f"layers_{i}"]["mixer"]["B_real"]) != 0).any(axis=1) |
+                 (np.asarray(ex[f"layers_{i}"]["mixer"]["B_imag"]) != 0).any(axis=1)).sum()) for i in range(nl)]
+    assert [_lib.lib.s5fxp_model_live_states(eng._h, i) for i in range(nl)] == live
+    assert all(n <= P // 2 for n in live), live          # the N-DNS recipe: two thirds of the states are dead
+    cm = cref.CModel(model.export())
+    B, L = 3, 333
+    fx = _input(qc, dims, B, L, seed=21)
+    ref, _, _, rtr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+    tops = [max(int(np.abs(t["xs_re"]).max()), int(np.abs(t["xs_im"]).max())) for t in rtr]
+    bounds = [_lib.lib.s5fxp_model_recurrence_xmax(eng._h, i) for i in range(nl)]   # of the top rung, over the live states
+    x = torch.from_numpy(fx.data).cuda()
+    slots = lambda e: [int(v) for v in e.lane_status(0).cpu().numpy()[8 + 6:8 + 8 * nl:8]]
+    for flags in (_lib.FWD_DEFER_REDO, _lib.FWD_DEFER_REDO | _lib.FWD_NO_PAIR, 0, _lib.FWD_EXACT):
+        y = torch.empty((B, L, dims["d_out"]), dtype=torch.int32, device="cuda")
+        eng.enqueue(x, fx.bits, fx.exp, y, B, L, flags=flags)
+        redo = bool(int(eng.check_status()[0]) & _lib.ST_REDO)
+        assert slots(eng) == [P // 2] * nl, (flags, slots(eng))
+        if flags == _lib.FWD_DEFER_REDO:   # the top rung asks for a repeat exactly when a live state passes its bound
+            assert redo == any(t > b for t, b in zip(tops, bounds)), (tops, bounds)
+        else:
+            assert not redo, flags
+        if not redo:
+            assert np.array_equal(y.cpu().numpy(), ref), flags
+    # with the carry in play every state slot is live as far as the kernels know
+    y, st = eng.forward_chunk(FxpArray(fx.data, fx.bits, fx.exp), None)
+    assert slots(eng) == [P] * nl and np.array_equal(y.numpy(), ref)
+    # the same model without the compaction
+    monkeypatch.setenv("S5FXP_NO_COMPACT", "1")
+    eng2 = build_regression_model(md, qc, dims["n_layers"]).engine()
+    monkeypatch.delenv("S5FXP_NO_COMPACT")
+    y2 = eng2.forward(FxpArray(fx.data, fx.bits, fx.exp))
+    assert slots(eng2) == [P] * nl and np.array_equal(y2.numpy(), ref)
+
+
 @pytest.mark.parametrize("case", ["tiny_bnsb", "ndns05"])
 def test_layer_forward_entry_point_matches_the_oracle_layer_by_layer(case):
     """s5fxp_layer_forward (FxpSequenceLayer.forward, fxpmodel.py:1110-1161): feeding the oracle's
