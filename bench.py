@@ -103,10 +103,12 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline repeats its pass until this much time has gone")
     ap.add_argument("--global-exponents", action="store_true", help="mode A: all-reduce(MAX) the exponent maxima")
     ap.add_argument("--inflight", type=int, default=3, help="launch sets in flight (streams); 1 = one at a time")
-    ap.add_argument("--groups", type=int, default=16,
+    ap.add_argument("--groups", type=int, default=8,
                     help="reference batches per launch set (s5fxp_forward_opts::groups): G independent batches of --batch sequences, each "
                          "its own compute_best batch, enqueued as one set of kernel launches; a step is still ONE batch")
     ap.add_argument("--no-scan-sweep", action="store_true", help="skip the extra recurrence-kernel measurement at 4x batch")
+    ap.add_argument("--no-one-batch-pass", action="store_true",
+                    help="skip the extra pass of plain one-batch forwards (profiling runs that want only the grouped launches)")
     ap.add_argument("--self-contained", action="store_true",
                     help="enqueue the gated exact re-run kernels with every forward (no status check needed)")
     args = ap.parse_args()
@@ -314,6 +316,7 @@ def main() -> None:
     single, ev1 = None, None
     if depth > 1 or G > 1:
         ev1 = make_events(n_sets(args.steps, G))
+        run(G, 1)  # lane 0's workspace for G groups exists before the clock starts
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         run(args.steps, 1, ev1)
@@ -324,7 +327,7 @@ def main() -> None:
                       scan_avg_kernel_us=round(scan_avg(ev1) * 1e6, 2), batches_per_launch=G)
     # ---- ... and plain forwards of ONE batch, one at a time: the launch the recurrence kernel's roofline is quoted on
     ev0 = None
-    if G > 1:
+    if G > 1 and not args.no_one_batch_pass:
         k0 = min(args.steps, 12 * nl)
         ev0 = make_events(k0)
         torch.cuda.synchronize()
@@ -366,7 +369,11 @@ def main() -> None:
     opt_kernel = {0: "k_scan_lane", 1: "k_scan_quad_asm", 2: "k_scan_quad_asm16", 3: "k_scan_pair_asm", 4: "k_scan_pairl_asm"}[max(kinds)]
     scan_kernel = opt_kernel if optimistic else ("k_scan_quad32_asm" if exact_mode else "k_scan_quad_asm")
     traffic = pmc_traffic(B, L, dims["P"], scan_kernel)
-    stored = scan_stored_bytes(scan_kernel, algo_bytes)
+    # a layer compacted to its live states (s5fxp_model_live_states) runs the recurrence on half the state slots: status word
+    # [8 + 8l + 6] of the last forward says how many (the algorithmic bytes stay 16 * P: the dead states are part of the model)
+    stw = eng.lane_status(lanes_of(1)[0]).cpu().numpy()
+    slots = [int(stw[8 + 8 * i + 6]) or dims["P"] for i in range(nl)]
+    stored = scan_stored_bytes(scan_kernel, algo_bytes) * sum(slots) // (nl * dims["P"])
     moved = traffic if traffic is not None else stored
     def roof(bytes_algo, bytes_moved, seconds):
         """SURVEY.md 8(d): `frac` is quoted on the ALGORITHMIC bytes (16*P per frame, the reference's int32 element type);
@@ -385,7 +392,7 @@ def main() -> None:
                     stream_width="int32 arithmetic; " + ("int16 range-guarded streams (Bu in, states out): every stored state is checked against the "
                                                          "kernel's exactness bound by its consumer" if stored < algo_bytes else "int32 streams"),
                     moved_bytes_source="PMC (profiles/r0N_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "stream sizes",
-                    launch=f"one reference batch per launch (B={B}), one launch at a time",
+                    launch=f"one reference batch per launch (B={B}), one launch at a time", state_slots_per_layer=slots,
                     measured="HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per launch set",
                     avg_kernel_us_in_the_timed_region=round(scan_inflight_s * 1e6, 2), batches_per_launch_in_the_timed_region=G)
     if ev1 is not None and G > 1:  # the same kernel on the launches the headline is made of: G batches per launch, nothing else running

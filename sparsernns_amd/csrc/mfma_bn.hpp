@@ -228,16 +228,16 @@ struct ResidHead {
 
 constexpr int RESID_THREADS = 384;
 template <bool RESID>
-__global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16_t *__restrict__ z, const int16_t *__restrict__ skip,
-                                                                  int16_t *__restrict__ out, int32_t *tr_resid, int64_t N, int H,
-                                                                  int64_t span, int res_bits, int skip_bits, ResidHead hd,
+__global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16_t *z_, const int16_t *skip_, int16_t *out_, int32_t *tr_resid,
+                                                                  int64_t N, int H, int64_t span, int res_bits, int skip_bits, ResidHead hd,
                                                                   float *ext, int ext_reps, int32_t *status, GroupOff go)
 {
-    {
-        const int64_t g = blockIdx.y;
-        gshift_nn(z, g * go.ws); gshift_nn(skip, g * go.ws); gshift_nn(out, g * go.ws); gshift(ext, g * go.ws);
-        gshift_nn(hd.d, g * go.ws); gshift(hd.skip_e.dyn, g * go.ws); gshift_nn(hd.status_exps, g * go.status); gshift_nn(status, g * go.status);
-    }
+    // this group's tensors (scan_quad.hpp GroupOff); the three streams keep their no-alias promise
+    const int64_t gws = (int64_t)blockIdx.y * go.ws, gst = (int64_t)blockIdx.y * go.status;
+    const int16_t *__restrict__ z = reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(z_) + gws);
+    const int16_t *__restrict__ skip = reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(skip_) + gws);
+    int16_t *__restrict__ out = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(out_) + gws);
+    gshift(ext, gws); gshift_nn(hd.d, gws); gshift(hd.skip_e.dyn, gws); gshift_nn(hd.status_exps, gst); gshift_nn(status, gst);
     __shared__ int32_t smin[RESID_THREADS * 8], smax[RESID_THREADS * 8];
     __shared__ AddCb sp;
     const int G = H >> 3, R = RESID_THREADS / G;
@@ -245,21 +245,29 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
     // a round = four frames per thread.  The first round's loads are issued BEFORE the head below: its exponent arithmetic
     // needs the maxima, the loads do not.  (Double-buffering every round was tried: 171 registers, one workgroup per CU
     // instead of three, 29 us instead of 23.)
-    const int64_t stride = R;
-    const int64_t lo_n = (int64_t)blockIdx.x * span, hi_n = lo_n + span < N ? lo_n + span : N;
-    auto fetch = [&](v4i(&zq)[4], v4i(&sq)[4], int64_t n0) {
+    // frames of this workgroup: [lo_n, lo_n + cnt).  Everything inside is addressed as a wave-uniform base (the workgroup's
+    // first frame) plus a 32-bit byte offset per thread: no 64-bit address arithmetic in the loop (the kernel sits at the
+    // 96 registers that three workgroups per CU allow)
+    const int64_t lo_n = (int64_t)blockIdx.x * span;
+    const int cnt = (int)((lo_n + span < N ? lo_n + span : N) - lo_n);
+    const char *zb = reinterpret_cast<const char *>(z + lo_n * H), *sb = reinterpret_cast<const char *>(skip + lo_n * H);
+    char *ob = reinterpret_cast<char *>(out + lo_n * H);
+    const unsigned rowb = 2u * (unsigned)H;                       // bytes per frame
+    const unsigned toff = (unsigned)rl * rowb + 16u * (unsigned)g; // this thread's first vector
+    const unsigned kstep = (unsigned)R * rowb;                    // R frames further
+    auto fetch = [&](v4i(&zq)[4], v4i(&sq)[4], int i0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t n = n0 + k * stride;
-            if (n < hi_n) {
-                zq[k] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(z + n * H + 8 * g));
-                if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(skip + n * H + 8 * g);
+            if (i0 + k * R + rl < cnt) {
+                const unsigned o = toff + (unsigned)(i0 / R) * kstep + (unsigned)k * kstep;
+                zq[k] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(zb + o));
+                if constexpr (RESID) sq[k] = *reinterpret_cast<const v4i *>(sb + o);
             }
         }
     };
     v4i za[4], sa[4];
-    const int64_t first = lo_n + rl, step = 4 * stride;
-    if (first < hi_n) fetch(za, sa, first);
+    const int first = rl, step = 4 * R; // frame indices relative to lo_n; i0 - rl is always a multiple of R
+    if (first < cnt) fetch(za, sa, 0);
     AddCb p{};
     if constexpr (RESID) {
         if (hd.enable) {
@@ -282,23 +290,23 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
         lo[e] = 32767;
         hi[e] = -32768;
     }
-    auto process = [&](const v4i(&zq)[4], const v4i(&sq)[4], int64_t n0) {
+    auto process = [&](const v4i(&zq)[4], const v4i(&sq)[4], int i0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t n = n0 + k * stride;
-            if (n < hi_n) {
+            if (i0 + k * R + rl < cnt) {
                 int32_t v[8], s[8];
                 unpack8_i16(zq[k], v);
                 if constexpr (RESID) {
                     unpack8_i16(sq[k], s);
+                    const unsigned o = toff + (unsigned)(i0 / R) * kstep + (unsigned)k * kstep;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
-                        if (tr_resid) tr_resid[n * H + 8 * g + e] = rr;
+                        if (tr_resid) tr_resid[lo_n * H + (o >> 1) + e] = rr;
                         v[e] = rr < 0 ? 0 : rr;
                     }
                     const v2i a = pack4_i16(v[0], v[1], v[2], v[3]), b = pack4_i16(v[4], v[5], v[6], v[7]);
-                    *reinterpret_cast<v4i *>(out + n * H + 8 * g) = v4i{a[0], a[1], b[0], b[1]};
+                    *reinterpret_cast<v4i *>(ob + o) = v4i{a[0], a[1], b[0], b[1]};
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
             }
         }
     };
-    for (int64_t n0 = first; n0 < hi_n; n0 += step) {
-        process(za, sa, n0);
-        if (n0 + step < hi_n) fetch(za, sa, n0 + step);
+    for (int i0 = 0; i0 + rl < cnt; i0 += step) {
+        process(za, sa, i0);
+        if (i0 + step + rl < cnt) fetch(za, sa, i0 + step);
     }
     if (!ext) return;
 #pragma unroll

@@ -388,7 +388,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
     // residual / extremes pass: a workgroup owns rm_span consecutive frames, a multiple of its 4 x R frame step
     const int64_t rm_step = 4 * (RESID_THREADS / (H / 8)), rm_iters = (N + rm_step - 1) / rm_step;
-    const int64_t rm_per = (rm_iters + cap_resid - 1) / cap_resid, rm_span = rm_per * rm_step;
+    // (the kernel addresses a workgroup's span with 32-bit byte offsets: at most 2^31 bytes of one (N,H) int16 tensor per workgroup)
+    const int64_t rm_per_max = std::max<int64_t>(1, ((int64_t(1) << 31) / (2 * H)) / rm_step);
+    const int64_t rm_per = std::min(rm_per_max, (rm_iters + cap_resid - 1) / cap_resid), rm_span = rm_per * rm_step;
     const unsigned rm_grid = (unsigned)((rm_iters + rm_per - 1) / rm_per);
 
     int16_t *h = I16(w.hA), *hn = I16(w.hB);
