@@ -33,17 +33,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(B, L, P, kernel):
-    """HBM bytes per recurrence launch from the committed PMC passes (profiles/r0N_scan_traffic.json: FETCH_SIZE
-    doubled per MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), if they were taken on this workload."""
-    for name in ("r02_scan_traffic.json", "r01_scan_traffic.json"):
-        p = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(p):
-            continue
-        with open(p) as f:
-            t = json.load(f)
-        if (t["B"], t["L"], t["P"]) == (B, L, P) and kernel in t["kernels"]:
-            return t["kernels"][kernel]["traffic_bytes_per_launch"]
+def pmc_traffic(B, L, P, kernel, groups, slots):
+    """HBM bytes per recurrence launch from the committed PMC passes (profiles/r03_scan_traffic.json: FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction, + WRITE_SIZE), if they were taken on this workload: same shape, same batches per
+    launch, same state slots per layer."""
+    p = os.path.join(ROOT, "profiles", "r03_scan_traffic.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        t = json.load(f)
+    if (t["B"], t["L"], t["P"]) != (B, L, P) or list(t["state_slots"]) != list(slots):
+        return None
+    for e in t["entries"]:
+        if e["batches_per_launch"] == groups and kernel in e["traffic_bytes_per_launch"]:
+            return e["traffic_bytes_per_launch"][kernel]
     return None
 
 
@@ -183,6 +186,12 @@ def main() -> None:
         allreduce = make_exponent_allreduce(via_host=dist.get_backend() != "nccl")
     model = build_regression_model(md, qc, dims["n_layers"])
     eng = model.engine()
+    # S5FXP_BENCH_IGNORE_STATUS=1: timing of ABLATED builds only (tools/variant.py: their results are wrong by design and
+    # would otherwise walk down the ladder or abort the run); never set for a number that is reported
+    ablated = os.environ.get("S5FXP_BENCH_IGNORE_STATUS") == "1"
+    if ablated:
+        _lib.ST_REDO = 0
+        eng.check_status = lambda lane=0: np.zeros(_lib.STATUS_WORDS, dtype=np.int32)
     # `inflight` batches are kept in flight, each on its own HIP stream and engine lane (engine.InflightRunner): the
     # recurrence of one batch (a latency chain on B*P/16 waves) overlaps the projections of the others.  Every lane
     # has its own resident input and output; a step = one forward over one batch, as before.
@@ -368,12 +377,12 @@ def main() -> None:
         kinds = {min(k, 2) for k in kinds}
     opt_kernel = {0: "k_scan_lane", 1: "k_scan_quad_asm", 2: "k_scan_quad_asm16", 3: "k_scan_pair_asm", 4: "k_scan_pairl_asm"}[max(kinds)]
     scan_kernel = opt_kernel if optimistic else ("k_scan_quad32_asm" if exact_mode else "k_scan_quad_asm")
-    traffic = pmc_traffic(B, L, dims["P"], scan_kernel)
     # a layer compacted to its live states (s5fxp_model_live_states) runs the recurrence on half the state slots: status word
     # [8 + 8l + 6] of the last forward says how many (the algorithmic bytes stay 16 * P: the dead states are part of the model)
     stw = eng.lane_status(lanes_of(1)[0]).cpu().numpy()
     slots = [int(stw[8 + 8 * i + 6]) or dims["P"] for i in range(nl)]
     stored = scan_stored_bytes(scan_kernel, algo_bytes) * sum(slots) // (nl * dims["P"])
+    traffic = pmc_traffic(B, L, dims["P"], scan_kernel, 1, slots)
     moved = traffic if traffic is not None else stored
     def roof(bytes_algo, bytes_moved, seconds):
         """SURVEY.md 8(d): `frac` is quoted on the ALGORITHMIC bytes (16*P per frame, the reference's int32 element type);
@@ -391,12 +400,22 @@ def main() -> None:
                     **roof(algo_bytes, moved, scan_avg_s),
                     stream_width="int32 arithmetic; " + ("int16 range-guarded streams (Bu in, states out): every stored state is checked against the "
                                                          "kernel's exactness bound by its consumer" if stored < algo_bytes else "int32 streams"),
-                    moved_bytes_source="PMC (profiles/r0N_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "stream sizes",
+                    moved_bytes_source="PMC (profiles/r03_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "stream sizes",
                     launch=f"one reference batch per launch (B={B}), one launch at a time", state_slots_per_layer=slots,
                     measured="HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per launch set",
                     avg_kernel_us_in_the_timed_region=round(scan_inflight_s * 1e6, 2), batches_per_launch_in_the_timed_region=G)
-    if ev1 is not None and G > 1:  # the same kernel on the launches the headline is made of: G batches per launch, nothing else running
-        roofline["grouped_launch"] = dict(batches_per_launch=G, **roof(G * algo_bytes, G * stored, scan_avg(ev1)))
+    if ev1 is not None and G > 1:
+        # The timed region is made of launches of G batches: THAT launch is the one the top-level figures describe (its algorithmic
+        # bytes are G x 16 P B L; it moves a quarter to a half of them, so its fraction is quoted on the moved bytes: roof()).  The
+        # plain one-batch launch -- a latency chain on B * P / 32 workgroups, the launch SURVEY.md 8(d) and the north star's
+        # "40 % on the scan kernel" speak of -- stays beside it.
+        tg = pmc_traffic(B, L, dims["P"], scan_kernel, G, slots)
+        one = {k: roofline[k] for k in ("achieved", "frac", "frac_basis", "frac_algorithmic", "frac_moved", "avg_kernel_us", "traffic",
+                                        "algorithmic_bytes_per_launch", "moved_bytes_per_launch", "launch")}
+        roofline.update(roof(G * algo_bytes, tg if tg is not None else G * stored, scan_avg(ev1)))
+        roofline.update(traffic=tg, launch=f"{G} reference batches per launch (G x B = {G * B} sequences, one exponent group per batch), one launch "
+                                           "set at a time", moved_bytes_source="PMC (profiles/r03_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if tg is not None else "stream sizes",
+                        one_batch_launch=one)
 
     # ---- the recurrence kernel with more chains than one reference batch gives it (not the headline workload): at
     # B=32 its launch is a latency chain on 128 waves, whatever the bandwidth; the same kernel at 4x the batch shows
@@ -484,7 +503,8 @@ def main() -> None:
                                      "range-guarded recurrence streams (a value outside the guarded range repeats the batch on "
                                      "the exact int32 kernels)"),
             roofline=roofline, recurrence_kernel_at_4x_batch=scan_big, cpu_baseline=cpu, single_stream=single,
-            mode=fallback_note or ("optimistic" if optimistic else "self-contained"), status_bits=int(st0),
+            mode="ABLATED BUILD, STATUS IGNORED: not a result" if ablated else (fallback_note or ("optimistic" if optimistic else "self-contained")),
+            status_bits=int(st0),
             output_gather_ms=gather_ms, rank_values=rank_values)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -242,17 +242,21 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
         int t0, nvalid;
         tile_of<FT>(tile, sr, b0, t0, nvalid);
         const int64_t n0 = b0 * a.L + t0;
+        // wave-uniform bases of this tile; everything below is a 32-bit byte offset from them (no 64-bit address arithmetic per
+        // thread: the kernel sits at its register cap)
+        const char *ub = reinterpret_cast<const char *>(a.u + n0 * H), *kb = reinterpret_cast<const char *>(a.skip + n0 * H);
+        char *zb = reinterpret_cast<char *>(a.z + n0 * H);
         // ---- u and skip of this wave's units: requested first, consumed in the epilogues
         v2i uq[NU][4], sq[NU][4];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             int fo = 32 * (sub0 + u * SUBSTEP) + r;
             fo = fo < nvalid ? fo : nvalid - 1;
-            const int64_t n = n0 + fo;
+            const unsigned fb = 2u * (unsigned)(fo * H + ch0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uq[u][g] = *reinterpret_cast<const v2i *>(a.u + n * H + ch0 + 8 * g);
-                sq[u][g] = *reinterpret_cast<const v2i *>(a.skip + n * H + ch0 + 8 * g);
+                uq[u][g] = *reinterpret_cast<const v2i *>(ub + fb + 16 * g);
+                sq[u][g] = *reinterpret_cast<const v2i *>(kb + fb + 16 * g);
             }
         }
         // ---- phase A: stream items -> byte planes
@@ -294,9 +298,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                     if (PAIR) {
                         // one 8-step item per lane of the pair: this thread takes the half with its 4 steps from both.
                         // lane A: [im0 im2 | re1 re3], lane B: [re0 re2 | im1 im3] (per half)
-                        const int t = t0 + o;
-                        const int16_t *src = reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t >> 3, p, a.TB >> 1, P) << 1) + (t & 4);
-                        const v2i qa = *reinterpret_cast<const v2i *>(src), qb = *reinterpret_cast<const v2i *>(src + 8);
+                        // the tile's items of state group p >> 5 start at pair_word(b0, t0 >> 3, 32 (p >> 5), ...): uniform base + 32-bit offset
+                        const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t0 >> 3, 0, a.TB >> 1, P) << 1));
+                        const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
+                        const v2i qa = *reinterpret_cast<const v2i *>(xb + xo), qb = *reinterpret_cast<const v2i *>(xb + xo + 16);
                         w[0] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x05040100u);
                         w[1] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x05040100u);
                         w[2] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x07060302u);
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<0>(zp), kz, cvtf_h<0>(sp))));
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<1>(zp), kz, cvtf_h<1>(sp))));
                     }
-                    *reinterpret_cast<v2i *>(a.z + n * H + ch) = zo;
+                    *reinterpret_cast<v2i *>(zb + 2u * (unsigned)((32 * sub + r) * H + ch)) = zo;
                 }
             }
             if (!PK16 && 32 * sub + r < nvalid) {
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                         // (slots 9, 10) merely size the reference's intermediate bit width and are not needed
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cz, kz, cs)));
                     }
-                    *reinterpret_cast<v2i *>(a.z + n * H + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<v2i *>(zb + 2u * (unsigned)((32 * sub + r) * H + ch)) = pack4_i16(o[0], o[1], o[2], o[3]);
                 }
             }
         }
