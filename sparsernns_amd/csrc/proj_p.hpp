@@ -102,12 +102,13 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         int64_t b;
         int t, nv;
         tile_of(tl, sr, b, t, nv);
+        const char *xb = reinterpret_cast<const char *>(a.x + (b * a.L + t) * H); // wave-uniform; 32-bit byte offsets from here
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = threadIdx.x + NTHR * i;
             int f = v / VPF;
             f = f < nv ? f : nv - 1;
-            raw[i] = *reinterpret_cast<const v4i *>(a.x + (b * a.L + t + f) * H + 8 * (v % VPF));
+            raw[i] = *reinterpret_cast<const v4i *>(xb + 2u * (unsigned)(f * H + 8 * (v % VPF)));
         }
     };
     if (tile < tiles) fetch(tile);
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         int t0, nvalid;
         tile_of(tile, sr, b0, t0, nvalid);
         const int64_t n0 = b0 * a.L + t0;
+        char *ub = reinterpret_cast<char *>(a.u + n0 * H); // wave-uniform base of this tile's rows of u
         int8_t *xh = Xh + (it & 1) * PLANE, *xl = Xl + (it & 1) * PLANE;
         // ---- phase A: BatchNorm chain, u, byte planes
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                     reinterpret_cast<int32_t(&)[4]>(u[4]));
             if (f < nvalid) {
                 const v2i p0 = pack4_i16(u[0], u[1], u[2], u[3]), p1 = pack4_i16(u[4], u[5], u[6], u[7]);
-                *reinterpret_cast<v4i *>(a.u + n * H + 8 * og) = v4i{p0[0], p0[1], p1[0], p1[1]};
+                *reinterpret_cast<v4i *>(ub + 2u * (unsigned)(f * H + 8 * og)) = v4i{p0[0], p0[1], p1[0], p1[1]};
                 if (TRACE) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -215,7 +217,12 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                             // wave store fills 512 contiguous bytes
                             const int32_t o0 = __builtin_amdgcn_ds_swizzle(q[0], 0x401f), o2 = __builtin_amdgcn_ds_swizzle(q[2], 0x401f);
                             const v2i item = pack4_i16(o0, o2, q[1], q[3]);
-                            if (live) *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, (t0 + o) >> 2, p, cc, a.TB, PC)) = item;
+                            // pair16_half(b0, (t0 + o) >> 2, p, cc): the tile's first block of state group 0 is the uniform base
+                            if (live) {
+                                char *qb = reinterpret_cast<char *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, t0 >> 2, 0, 0, a.TB, PC));
+                                const unsigned qo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 6) + 2 * (p & 31) + cc) * 8) + 4 * ((o >> 2) & 1));
+                                *reinterpret_cast<v2i *>(qb + qo) = item;
+                            }
                         } else if (SM == 2) {
                             // K = (Bu << 16) + k.  Pair-native items: lane A = [Kim0 Kim2 Kre1 Kre3], lane B = [Kre0 Kre2
                             // Kim1 Kim3]: steps 0 and 2 come from the OTHER component's lane (r ^ 16, ds_swizzle), steps 1
@@ -514,9 +521,10 @@ __global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = threadIdx.x + 384 * i;
-            int64_t n = tl * FT + v / VPF;
-            n = n < a.N ? n : a.N - 1;
-            raw[i] = *reinterpret_cast<const v4i *>(a.x + n * H + 8 * (v % VPF));
+            const int64_t left = a.N - tl * FT; // frames from the tile's first to the end of the tensor (wave-uniform)
+            int f = v / VPF;
+            f = f < left ? f : (int)left - 1;
+            raw[i] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.x + tl * FT * H) + 2u * (unsigned)(f * H + 8 * (v % VPF)));
         }
     };
     int64_t tile = blockIdx.x;
@@ -554,13 +562,14 @@ __global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowl + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
             if (col < a.M) {
-                int32_t *dst = a.y + nb * a.M + col;
+                char *yb = reinterpret_cast<char *>(a.y + n0 * a.M); // wave-uniform base of the tile's output rows
+                const unsigned yo = 4u * (unsigned)((32 * sub + 4 * h) * a.M + col);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int fo = (i & 3) + 8 * (i >> 2);
                     if (nb + fo < a.N) {
                         const int32_t v = sat(asr(acc[i], rs), a.out_bits);
-                        dst[(int64_t)fo * a.M] = sat(wadd(v, bev[c]), a.out_bits);
+                        *reinterpret_cast<int32_t *>(yb + yo + 4u * (unsigned)(fo * a.M)) = sat(wadd(v, bev[c]), a.out_bits);
                     }
                 }
             }
