@@ -61,6 +61,16 @@ __global__ void k_select_maxima(LayerDyn *d)
 // No weights in LDS (35 KB at dim 0.5, 65 KB at dim 1.0), ~128 registers.
 // LDS: [cs_re][cs_im][D][cs_out2][bias_eff] (Np ints each) [lut pairs 8] [S hi][S lo][X1 hi][X1 lo] [red 3x16]
 // ---------------------------------------------------------------------------------------------
+// The barriers between the phases order LDS traffic only (planes written by some waves, read by others).  __syncthreads()
+// is a fence + barrier and the fence waits for EVERY outstanding memory operation (s_waitcnt vmcnt(0)): the loads requested
+// a tile ahead would be drained at the next barrier.  This one waits for the wave's LDS operations and nothing else.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int CTRL>
 __device__ __forceinline__ int32_t quad_xchg(int32_t v)
 {
@@ -235,6 +245,30 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
     v2i16 pmax = {0, 0}, pmin = {0, 0}; // S16: running extremes of (re, im) as packed int16
     float mx[3] = {0.f, 0.f, 0.f}; // [0]: |z*kz + s| as converted integers, scaled once at the end; [1], [2] stay 0
     const int ch0 = 32 * ct + 4 * h;
+    // u and skip of this wave's unit (32 frames x 32 channels), 8 bytes per lane and 8-channel group.  They are requested a
+    // whole tile ahead and IN TURN: the next tile's u goes into the registers the first epilogue has just emptied, the next
+    // tile's skip into those the second epilogue has emptied -- no extra registers, and the kernel has loads in flight during
+    // its arithmetic phases instead of one burst at the top of every tile (32 KB per tile and workgroup outstanding for a third
+    // of the tile's time is all that two workgroups per CU had in flight: ~3 TB/s by Little's law, which is what it ran at)
+    v2i uq[NU][4], sq[NU][4];
+    auto load_rows = [&](v2i(&dst)[NU][4], const int16_t *src, int64_t tl) {
+        int64_t b;
+        int t, nv;
+        tile_of<FT>(tl, sr, b, t, nv);
+        const char *base = reinterpret_cast<const char *>(src + (b * a.L + t) * H); // wave-uniform
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int fo = 32 * (sub0 + u * SUBSTEP) + r;
+            fo = fo < nv ? fo : nv - 1;
+            const unsigned fb = 2u * (unsigned)(fo * H + ch0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[u][g] = *reinterpret_cast<const v2i *>(base + fb + 16 * g);
+        }
+    };
+    if ((int64_t)blockIdx.x < tiles) {
+        load_rows(uq, a.u, blockIdx.x);
+        load_rows(sq, a.skip, blockIdx.x);
+    }
     __syncthreads();
 
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -242,23 +276,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
         int t0, nvalid;
         tile_of<FT>(tile, sr, b0, t0, nvalid);
         const int64_t n0 = b0 * a.L + t0;
-        // wave-uniform bases of this tile; everything below is a 32-bit byte offset from them (no 64-bit address arithmetic per
+        // wave-uniform base of this tile; everything below is a 32-bit byte offset from it (no 64-bit address arithmetic per
         // thread: the kernel sits at its register cap)
-        const char *ub = reinterpret_cast<const char *>(a.u + n0 * H), *kb = reinterpret_cast<const char *>(a.skip + n0 * H);
         char *zb = reinterpret_cast<char *>(a.z + n0 * H);
-        // ---- u and skip of this wave's units: requested first, consumed in the epilogues
-        v2i uq[NU][4], sq[NU][4];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            int fo = 32 * (sub0 + u * SUBSTEP) + r;
-            fo = fo < nvalid ? fo : nvalid - 1;
-            const unsigned fb = 2u * (unsigned)(fo * H + ch0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uq[u][g] = *reinterpret_cast<const v2i *>(ub + fb + 16 * g);
-                sq[u][g] = *reinterpret_cast<const v2i *>(kb + fb + 16 * g);
-            }
-        }
+        const int64_t tile_next = tile + gridDim.x;
         // ---- phase A: stream items -> byte planes
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                 *reinterpret_cast<int32_t *>(Sh + row + P) = (int32_t)perm(u23, u01, 0x07060302u);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- phase B1: C projection + first epilogue
         int32_t x1v[NU][16];
         uint32_t x1p[NU][8]; // PK16: the same values as int16 pairs (channels 2q, 2q+1 of group g at [2g + q])
@@ -409,7 +430,8 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                 }
             }
         }
-        __syncthreads();
+        if (tile_next < tiles) load_rows(uq, a.u, tile_next); // the first epilogue is done with u
+        lds_barrier();
         // ---- phase B2: out2 + second epilogue
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -492,6 +514,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                 }
             }
         }
+        if (tile_next < tiles) load_rows(sq, a.skip, tile_next); // the second epilogue is done with skip
     }
     // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
     if (S16) {

@@ -782,7 +782,7 @@ def test_w4a8_tracks_w8a16_within_the_stated_tolerance():
     from sparsernns_amd.fxparray import FxpArray
     from sparsernns_amd.fxpmodel import build_regression_model
 
-    outs = {}
+    outs, enc = {}, {}
     for q in ("w8a16", "w4a8"):
         md, qc, dims = _make(dict(dim_scale=1.0, quantization=q, input_scale=300.0, calib_L=256))
         model = build_regression_model(md, qc, dims["n_layers"])
@@ -791,10 +791,25 @@ def test_w4a8_tracks_w8a16_within_the_stated_tolerance():
         ref, _, re_, _ = cref.CModel(model.export()).forward(fx.data, fx.bits, fx.exp)
         assert np.array_equal(y.numpy(), ref), q
         outs[q] = ref.astype(np.float64) / (1 << re_)
+        inter = {}
+        O.RegressionModel(md, qc, dims["n_layers"])(fx, inter)
+        e = O.flatten_intermediates(inter)["encoder_output"]
+        enc[q] = (e.data.astype(np.float64) / 2.0 ** e.exp, qc["encoder"], np.asarray(md["encoder"]["encoder"]["kernel"], dtype=np.float64))
     d = outs["w4a8"] - outs["w8a16"]
     rel = np.linalg.norm(d) / np.linalg.norm(outs["w8a16"])
     corr = np.corrcoef(outs["w4a8"].ravel(), outs["w8a16"].ravel())[0, 1]
     assert rel < W4A8_REL_L2_BOUND and corr > W4A8_CORR_BOUND, (rel, corr)
+    # Where the tolerance CAN be derived -- one dense layer, no accumulated nonlinearity -- it is: rounding a weight to a step of
+    # 2^-w_exp adds uniform noise of variance step^2 / 12, so the encoder outputs of the two recipes must differ by a relative L2
+    # error of (2^-w_exp / sqrt 12) / rms(kernel), plus the (small) input and output steps.  A wrong exponent, a dropped byte
+    # plane or a saturating weight would land far outside [0.5, 1.5] x that figure (measured 0.161 against 0.147).
+    a4, q4, kern = enc["w4a8"]
+    a8 = enc["w8a16"][0]
+    x_rms = float(np.sqrt(np.mean((fx.data.astype(np.float64) / 2.0 ** fx.exp) ** 2)))
+    pred = np.sqrt((2.0 ** -q4["w_exp"] / np.sqrt(12) / np.sqrt(np.mean(kern ** 2))) ** 2 +
+                   (2.0 ** -q4["out_exp"] / np.sqrt(12) / np.sqrt(np.mean(a8 ** 2))) ** 2 + (2.0 ** -q4["inp_exp"] / np.sqrt(12) / x_rms) ** 2)
+    rel_enc = np.linalg.norm(a4 - a8) / np.linalg.norm(a8)
+    assert 0.5 * pred < rel_enc < 1.5 * pred, (rel_enc, pred)
 
 
 # measured (deterministic: both outputs are bit-exact with the oracle): rel L2 0.649, correlation 0.797
