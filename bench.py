@@ -290,27 +290,26 @@ def main() -> None:
     fallback_note = None
     # setup, not warmup: one forward per lane so that every lane's workspace and status words exist and every kernel
     # has been loaded before anything is timed, however small --warmup / --steps are
-    run(depth * G, depth)
-    torch.cuda.synchronize()
-    probe = max(args.warmup, 1)
-    run(probe, depth)
-    torch.cuda.synchronize()
-    bits = 0
-    for lane in lanes_of(depth):
-        bits |= int(eng.check_status(lane)[0])
+    def setup_pass():  # every lane runs a full launch set: every batch of the input pool has been through the kernels
+        run(depth * G, depth)
+        torch.cuda.synchronize()
+        b = 0
+        for lane in lanes_of(depth):
+            b |= int(eng.check_status(lane)[0])
+        return b
+
+    bits = setup_pass()
     while (bits & _lib.ST_REDO) and eng.level < 2:
         # climb the ladder before anything is timed: pair kernel -> quad kernel (int16 streams, full 16-bit bound) -> exact
         eng.level += 1
         fallback_note = ("states left the pair kernel's range: quad recurrence kernel (int16 streams) for every step" if eng.level == 1
                          else "states left the 16-bit fast range: exact kernels (S5FXP_FWD_EXACT) for every step")
         exact_mode = eng.level == 2
-        run(probe, depth)
-        torch.cuda.synchronize()
-        bits = 0
-        for lane in lanes_of(depth):
-            bits |= int(eng.check_status(lane)[0])
+        bits = setup_pass()
     if bits & _lib.ST_REDO:
         raise SystemExit("the exact kernels reported ST_REDO: this cannot happen")
+    run(args.warmup, depth)  # the W untimed warmup steps
+    torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     events = make_events(n_sets(args.steps, G))

@@ -123,6 +123,27 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         for (int ks = 0; ks < KS; ++ks)
             wreg[c][ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)col * a.w.Kp + 32 * ks + 16 * h);
     }
+#ifdef S5_BPROJ_CSR
+    // EXPERIMENT build only (-DS5_BPROJ_CSR=<max nonzeros per column>; tools/variant.py): the
+    // weight operand as compressed columns -- per output column the (k, w) pairs of its nonzeros, padded to the widest
+    // column of the wave -- and the contraction on the VALU, one multiply-add per (frame, nonzero) and byte plane,
+    // instead of the dense zero-filled MFMA operand.  Same accumulators, same epilogue, same results.
+    constexpr int ELLW = S5_BPROJ_CSR;
+    uint16_t *ell = reinterpret_cast<uint16_t *>(smem + 16 * H + 4 * PLANE); // [32 * NC columns][ELLW]: k | w << 8
+    int *ellmax = reinterpret_cast<int *>(ell + 32 * NC * ELLW);            // [NC]: widest column of the tile
+    if (threadIdx.x < NC) ellmax[threadIdx.x] = 0;
+    __syncthreads();
+    if (wsub == 0 && h == 0) {
+        const int col = 32 * wct + r;
+        int n = 0;
+        for (int k = 0; k < H; ++k) {
+            const int8_t wv = a.w.wt[(size_t)col * a.w.Kp + k];
+            if (wv != 0 && n < ELLW) ell[col * ELLW + n++] = (uint16_t)(k | ((unsigned)(uint8_t)wv << 8));
+        }
+        for (int j = n; j < ELLW; ++j) ell[col * ELLW + j] = 0;
+        atomicMax(ellmax + wct, n);
+    }
+#endif
     // The BatchNorm exponents of this layer: read from *dyn, or -- single-rank forwards -- derived here, by every
     // workgroup for itself, from the per-channel extremes the producer of the layer input left behind (the first tile's
     // loads are in flight meanwhile).  A single workgroup doing this at the tail of the producer kernel cost 4-7 us of
@@ -183,6 +204,28 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                 const int sub = sub0 + wsub;
                 const int8_t *rowh = xh + (32 * sub + r) * KP + 16 * h, *rowl = xl + (32 * sub + r) * KP + 16 * h;
                 v16i acc;
+#ifdef S5_BPROJ_CSR
+                {
+                    (void)rowh; (void)rowl;
+                    int32_t ah[16], al[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ah[i] = al[i] = 0;
+                    const uint16_t *mine = ell + (32 * (wct + NC * c) + r) * ELLW;
+                    const int nz = ellmax[wct + NC * c];
+                    for (int j = 0; j < nz; ++j) {
+                        const unsigned e = mine[j];
+                        const int k = e & 0xff, wv = (int8_t)(e >> 8);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int f = 32 * sub + 8 * (i >> 2) + 4 * h + (i & 3);
+                            ah[i] += wv * xh[f * KP + k];
+                            al[i] += wv * xl[f * KP + k];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] = wadd(wadd(wshl(ah[i], 8), csv[c]), al[i]);
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0;
 #pragma unroll
@@ -193,6 +236,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowl + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
+#endif
                 // rows (frames) (i&3) + 8*(i>>2) + 4*h of this half: registers 4g..4g+3 are one 4-step block
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {

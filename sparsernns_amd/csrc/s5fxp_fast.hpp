@@ -502,7 +502,11 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 a.ext_reps = EXT_REPS; a.status = status; a.status_exps = st_exps;
             }
             // phase-split kernel (proj_p.hpp): 64-step tiles, up to 4 (H=96) / 2 (H=192) workgroups per CU
+#ifdef S5_BPROJ_CSR
+            const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16) + 2 * (size_t)(2 * m->P) * S5_BPROJ_CSR + 64; // + compressed columns
+#else
             const size_t smem = 16 * (size_t)H + 4 * 64 * (size_t)(H + 16); // BN operands + double-buffered byte planes
+#endif
             {
                 a.t_lo = 0; a.t_len = L;
                 const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), cap = big ? cap_bproj / 2 : cap_bproj, per = (tl + cap - 1) / cap;
