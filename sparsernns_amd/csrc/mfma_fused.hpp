@@ -66,7 +66,11 @@ __global__ void k_select_maxima(LayerDyn *d)
 // a tile ahead would be drained at the next barrier.  This one waits for the wave's LDS operations and nothing else.
 __device__ __forceinline__ void lds_barrier()
 {
+#ifdef S5_BARRIER_VM0
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -179,7 +183,18 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // packs, clamped packed sub / mad / add, SDWA half-word operands -- about a third fewer VALU instructions, same results
 template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false, bool PK16 = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
-__global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const CGateArgs a_k, GroupOff go)
+// -DS5_CGATE_HID=1: states, u and skip of the NEXT tile all requested a tile ahead behind the compiler's back and waited for
+// by exact count (scan_quad.hpp vm_wait).  Measured (profiles/r03_gate_prefetch_ab.txt): 226 us per 8-batch launch against
+// 210 us for the default below, which requests the states at the top of the tile that uses them and lets the compiler's
+// vmcnt(0) there drain the skip prefetch as well -- MORE bytes in flight make this kernel slower, not faster (the same
+// build with every barrier draining all loads: 245 us).  Kept as the experiment's record.
+#ifndef S5_CGATE_HID
+#define S5_CGATE_HID 0
+#endif
+#ifndef S5_CGATE_LB
+#define S5_CGATE_LB 4
+#endif
+__global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGATE_LB : 3) void k_cgate_p(const CGateArgs a_k, GroupOff go)
 {
     CGateArgs a = a_k; // (the LUT is indexed by thread below: that read stays on the kernel argument, so that this copy lives in registers)
     {
@@ -191,6 +206,8 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
     constexpr int KPS = 2 * P + 16, KPX = H + 16;
     constexpr int NU = 1, SUBSTEP = 0;   // units per wave
     constexpr int ITEMS = (FT / 4) * P, ROUNDS = (ITEMS + NTHR - 1) / NTHR;
+    // hidden prefetches, see below (the dim 1.0 kernel on all 128 state slots has no registers left for them)
+    constexpr bool HID = S5_CGATE_HID && S16 && PAIR && PK16 && !WIDE && !TRACE && KS * NT < 24;
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];
     int32_t *csr = reinterpret_cast<int32_t *>(smem), *csi = csr + H, *Dl = csi + H, *cs2 = Dl + H, *be = cs2 + H, *lutp = be + H;
     int32_t *sigt = lutp + 8; // SIGTAB_WORDS, or the direct table (int16, SIGDIR_BYTES)
@@ -262,15 +279,47 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
             fo = fo < nv ? fo : nv - 1;
             const unsigned fb = 2u * (unsigned)(fo * H + ch0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) dst[u][g] = *reinterpret_cast<const v2i *>(base + fb + 16 * g);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (HID) dst[u][g] = gload8_hidden(base, fb + 16 * g);
+                else dst[u][g] = *reinterpret_cast<const v2i *>(base + fb + 16 * g);
+            }
+        }
+    };
+    // ... and so are the recurrence's states on the pair rung (the shipped path): phase A's two 8-byte loads per item used to
+    // be issued and consumed on the spot, every tile opening with one exposed round trip to memory
+    // On that path the three prefetches are issued behind the compiler's back and waited for by count (scan_quad.hpp
+    // vm_wait): the wait its own pass puts in front of their first use, a tile later and behind conditional stores, is
+    // vmcnt(0) -- which also drains whatever was requested since.  Memory operations of a wave on a full tile, in order:
+    //   phase A: [x(next): NX]   B1: [u(next): 4]   B2: [z stores: 4] [skip(next): 4]
+    constexpr bool XPRE = HID;
+    constexpr int NX_MIN = 2 * (ITEMS / NTHR); // x loads every wave issues per tile (waves of the last round: two more)
+    v2i xq[XPRE ? ROUNDS : 1][2];
+    auto load_x = [&](int64_t tl) {
+        int64_t b;
+        int t, nv;
+        tile_of<FT>(tl, sr, b, t, nv);
+        const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b, t >> 3, 0, a.TB >> 1, P) << 1));
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            const int q = threadIdx.x + NTHR * i;
+            if (ROUNDS * NTHR == ITEMS || q < ITEMS) {
+                const int grp = q / P, p = q % P;
+                int o = 4 * grp;
+                if (o >= nv) o = (nv - 1) & ~3;
+                const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
+                xq[i][0] = gload8_hidden(xb, xo);
+                xq[i][1] = gload8_hidden(xb, xo + 16);
+            }
         }
     };
     if ((int64_t)blockIdx.x < tiles) {
+        if constexpr (XPRE) load_x(blockIdx.x);
         load_rows(uq, a.u, blockIdx.x);
         load_rows(sq, a.skip, blockIdx.x);
     }
     __syncthreads();
 
+    prologue_loads_done();
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         int64_t b0;
         int t0, nvalid;
@@ -280,6 +329,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
         // thread: the kernel sits at its register cap)
         char *zb = reinterpret_cast<char *>(a.z + n0 * H);
         const int64_t tile_next = tile + gridDim.x;
+        if constexpr (HID) vm_wait<12>(xq); // newer than this tile's states: u, the last tile's stores, skip
         // ---- phase A: stream items -> byte planes
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
@@ -320,9 +370,14 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                         // one 8-step item per lane of the pair: this thread takes the half with its 4 steps from both.
                         // lane A: [im0 im2 | re1 re3], lane B: [re0 re2 | im1 im3] (per half)
                         // the tile's items of state group p >> 5 start at pair_word(b0, t0 >> 3, 32 (p >> 5), ...): uniform base + 32-bit offset
-                        const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t0 >> 3, 0, a.TB >> 1, P) << 1));
-                        const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
-                        const v2i qa = *reinterpret_cast<const v2i *>(xb + xo), qb = *reinterpret_cast<const v2i *>(xb + xo + 16);
+                        v2i qa, qb;
+                        if constexpr (XPRE) {
+                            qa = xq[i][0]; qb = xq[i][1]; // load_x: requested a tile ago
+                        } else {
+                            const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t0 >> 3, 0, a.TB >> 1, P) << 1));
+                            const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
+                            qa = *reinterpret_cast<const v2i *>(xb + xo); qb = *reinterpret_cast<const v2i *>(xb + xo + 16);
+                        }
                         w[0] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x05040100u);
                         w[1] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x05040100u);
                         w[2] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x07060302u);
@@ -373,7 +428,11 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                 *reinterpret_cast<int32_t *>(Sh + row + P) = (int32_t)perm(u23, u01, 0x07060302u);
             }
         }
+        if constexpr (XPRE) {
+            if (tile_next < tiles) load_x(tile_next);
+        }
         lds_barrier();
+        if constexpr (HID) vm_wait<8>(uq); // newer: the last tile's stores, skip (and x(next), if there is a next tile)
         // ---- phase B1: C projection + first epilogue
         int32_t x1v[NU][16];
         uint32_t x1p[NU][8]; // PK16: the same values as int16 pairs (channels 2q, 2q+1 of group g at [2g + q])
@@ -432,6 +491,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
         }
         if (tile_next < tiles) load_rows(uq, a.u, tile_next); // the first epilogue is done with u
         lds_barrier();
+        if constexpr (HID) { // newer: x(next) and u(next), if there is a next tile
+            if (tile_next < tiles) vm_wait<NX_MIN + 4>(sq);
+            else vm_wait<0>(sq);
+        }
         // ---- phase B2: out2 + second epilogue
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -439,7 +502,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
             const int64_t n = n0 + 32 * sub + r;
             v16i acc;
             mfma_planes<NT>(acc, wo2, Xh + (32 * sub + r) * KPX + 16 * h, Xl + (32 * sub + r) * KPX + 16 * h, cs2 + ch0);
-            if (PK16 && 32 * sub + r < nvalid) {
+            auto b2_pk16 = [&]() {
                 // out2 bias, table sigmoid, gate (fxpmodel.py:1133-1137, :97-144, :1075-1093) on int16 pairs
                 const uint32_t lm = 0x10001u * (uint32_t)(1 << lq_l), lr = 0x10001u * (uint32_t)lq_r;
 #pragma unroll
@@ -462,6 +525,16 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 ? 4 : 3) void k_cgate_p(const
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<1>(zp), kz, cvtf_h<1>(sp))));
                     }
                     *reinterpret_cast<v2i *>(zb + 2u * (unsigned)((32 * sub + r) * H + ch)) = zo;
+                }
+            };
+            if constexpr (PK16) {
+                if (!HID) {
+                    if (32 * sub + r < nvalid) b2_pk16();
+                } else if (nvalid == FT) {
+                    b2_pk16(); // a full tile: no control flow around its stores, their number is known
+                } else {
+                    if (32 * sub + r < nvalid) b2_pk16();
+                    prologue_loads_done(); // behind conditional stores nothing is left in flight
                 }
             }
             if (!PK16 && 32 * sub + r < nvalid) {

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
     const Bn16 bn = bn16_setup(a.bn, d, tab, H);
     __syncthreads();
 
+    prologue_loads_done();
     for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
         int64_t b0;
         int t0, nvalid;
@@ -367,7 +368,7 @@ __device__ __forceinline__ void mfma_nplanes(v16i &acc, const v4i (&w)[KSTEPS], 
 // LDS: [cs128 Np][bias_eff Np][X hi][X lo][ext hi H][ext lo H]
 // ---------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float *ext, int ext_reps, GroupOff go)
+__global__ __launch_bounds__(384, 3) void k_enc_p(EncArgs a, float *ext, int ext_reps, GroupOff go)
 {
     {
         const int64_t g = blockIdx.y;
@@ -398,15 +399,21 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
         elo[i] = 0;
     }
     const CfgOp cv = make_cfg(a.conv != 0, a.xb, a.xe, a.inp_bits, a.inp_exp);
-    // rows wave, wave+6, ... of the tile; the first RA of them are prefetched across phase B, the rest are
-    // requested at the top of phase A and land while the first are converted (44 registers of prefetch would
-    // push the kernel over the 128 that two workgroups per CU allow)
-    constexpr int RA = 3, RB = RPW - RA;
-    v4i rawa[RA], rawb[RB];
-    auto row_ptr = [&](int64_t tl, int i) {
-        int64_t n = tl * FT + wave + NW * i;
+    // rows wave, wave+6, ... of the tile.  Two workgroups of six waves per CU are three waves per SIMD whatever the kernel
+    // does, so it may hold 168 registers: all of a tile's rows are requested a tile ahead (dim 0.5; the two-unit phase B
+    // of dim 1.0 has no room for that: there the first RA rows are prefetched and the rest requested at the top of phase A).
+    // The prefetch is issued behind the compiler's back (scan_quad.hpp vm_wait): its own wait at the first use -- a tile
+    // later, behind phase B's stores -- would be vmcnt(0), every tile opening with a wait for the previous tile's stores.
+    constexpr int RA = NT <= 3 ? RPW : 3, RB = RPW - RA;
+    v4i rawa[RA], rawb[RB > 0 ? RB : 1];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto row_base = [&](int64_t tl, int i) { // wave-uniform
+        int64_t n = tl * FT + wave_u + NW * i;
         n = n < a.N ? n : a.N - 1;
-        return reinterpret_cast<const v4i *>(a.x + n * K + 4 * l); // 4-byte aligned 16-byte load
+        return reinterpret_cast<const char *>(a.x + n * K);
+    };
+    auto row_ptr = [&](int64_t tl, int i) {
+        return reinterpret_cast<const v4i *>(row_base(tl, i) + 16 * l); // 4-byte aligned 16-byte load
     };
     auto convert_row = [&](const v4i &q, int f, bool &wide) {
         int32_t v[4] = {q[0], q[1], q[2], q[3]};
@@ -423,24 +430,34 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
     int64_t tile = blockIdx.x;
     if (tile < tiles) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) rawa[i] = *row_ptr(tile, i);
+        for (int i = 0; i < RA; ++i) rawa[i] = gload16_hidden(row_base(tile, i), 16u * (unsigned)l);
     }
     bool wide = false;
     __syncthreads();
     PHASE_DECL
+    prologue_loads_done();
+    const bool even = a.M == H; // no ragged column tile: full tiles store unconditionally
     for (; tile < tiles; tile += gridDim.x) {
         const int64_t n0 = tile * FT;
         PHASE_MARK(0, l); // loop top (includes the previous tile's closing barrier)
         // ---- phase A
+        // the prefetched rows are older than the previous tile's stores: NU x 4 per wave on the unconditional path (the
+        // conditional one ends with a full wait)
+        vm_wait<4 * NU>(rawa);
+        if constexpr (RB > 0) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) rawb[i] = *row_ptr(tile, RA + i);
+            for (int i = 0; i < RB; ++i) rawb[i] = *row_ptr(tile, RA + i);
+        }
 #pragma unroll
-        for (int i = 0; i < RA; ++i) convert_row(rawa[i], wave + NW * i, wide);
+        for (int i = 0; i < RA; ++i)
+            if (wave_u + NW * i < FT) convert_row(rawa[i], wave_u + NW * i, wide);
         PHASE_MARK(1, rawa[RA - 1][0]); // prefetched rows converted
+        if constexpr (RB > 0) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-            if (wave + NW * (RA + i) < FT) convert_row(rawb[i], wave + NW * (RA + i), wide);
-        PHASE_MARK(2, rawb[RB - 1][0]); // rows requested at the top (their HBM latency included)
+            for (int i = 0; i < RB; ++i)
+                if (wave_u + NW * (RA + i) < FT) convert_row(rawb[i], wave_u + NW * (RA + i), wide);
+        }
+        PHASE_MARK(2, rawb[0][0]); // rows requested at the top (their HBM latency included)
         for (int e = threadIdx.x; e < FT * rem; e += 384) { // the K-256 tail of every row
             const int f = e / rem, k = 256 + e % rem;
             int64_t n = n0 + f;
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
         }
         if (tile + gridDim.x < tiles) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) rawa[i] = *row_ptr(tile + gridDim.x, i); // in flight during phase B
+            for (int i = 0; i < RA; ++i) rawa[i] = gload16_hidden(row_base(tile + gridDim.x, i), 16u * (unsigned)l); // in flight during phase B
         }
         PHASE_MARK(3, l); // tail column + prefetch issue
         __syncthreads();
@@ -465,26 +482,32 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
             v16i acc;
             mfma_planes<KS>(acc, wreg, Xh + (32 * sub + r) * KP + 16 * h, Xl + (32 * sub + r) * KP + 16 * h, cs + ch0);
             PHASE_MARK(5, acc[15]); // operand reads + MFMA chain, complete
-            if (n < a.N) {
+            auto group = [&](int g) {
+                const int ch = ch0 + 8 * g;
+                const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
+                int32_t o[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = ch0 + 8 * g;
-                    if (ch < a.M) {
-                        const v4i bv = *reinterpret_cast<const v4i *>(be + ch);
-                        int32_t o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            int32_t v = sat(asr(acc[4 * g + e], a.rs), a.out_bits);
-                            v = sat(wadd(v, bv[e]), a.out_bits);
-                            o[e] = v < 0 ? 0 : v;
-                            // (v, 65535 - v) as a u16 pair; one packed max keeps both running extremes
-                            const uint32_t t = (uint32_t)__umul24((unsigned)o[e], 0x10001u) ^ 0xffff0000u;
-                            pk[4 * g + e] = __builtin_bit_cast(
-                                uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, pk[4 * g + e]), __builtin_bit_cast(v2u16, t)));
-                        }
-                        *reinterpret_cast<v2i *>(a.y + n * a.M + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    int32_t v = sat(asr(acc[4 * g + e], a.rs), a.out_bits);
+                    v = sat(wadd(v, bv[e]), a.out_bits);
+                    o[e] = v < 0 ? 0 : v;
+                    // (v, 65535 - v) as a u16 pair; one packed max keeps both running extremes
+                    const uint32_t t = (uint32_t)__umul24((unsigned)o[e], 0x10001u) ^ 0xffff0000u;
+                    pk[4 * g + e] = __builtin_bit_cast(
+                        uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u16, pk[4 * g + e]), __builtin_bit_cast(v2u16, t)));
                 }
+                *reinterpret_cast<v2i *>(a.y + n * a.M + ch) = pack4_i16(o[0], o[1], o[2], o[3]);
+            };
+            if (even && n0 + FT <= a.N) { // no control flow around the stores (see vm_wait above)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) group(g);
+            } else {
+                if (n < a.N) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (ch0 + 8 * g < a.M) group(g);
+                }
+                prologue_loads_done(); // nothing in flight behind a conditional store
             }
         }
         PHASE_MARK(6, pk[15]); // epilogue arithmetic done, stores issued
@@ -521,13 +544,15 @@ __global__ __launch_bounds__(384, NT <= 3 ? 4 : 2) void k_enc_p(EncArgs a, float
 }
 
 // ---------------------------------------------------------------------------------------------
+// where masked-off lanes of a store send their value instead (never read)
+__device__ int32_t g_store_sink[64];
 // Decoder, phase-split: h int16 (N,H) -> dense int32 (N,M), M <= 288.  fxpmodel.py:331-366, 1272-1274.
 // Six waves, 64-frame tiles.  Phase B runs as D = X * W (lane = output column, registers = frames): every
 // store instruction writes 128 contiguous bytes of one output row per half wave.
 // LDS: [X hi][X lo]
 // ---------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
+__global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
 {
     {
         const int64_t g = blockIdx.y;
@@ -568,13 +593,19 @@ __global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
             const int64_t left = a.N - tl * FT; // frames from the tile's first to the end of the tensor (wave-uniform)
             int f = v / VPF;
             f = f < left ? f : (int)left - 1;
-            raw[i] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.x + tl * FT * H) + 2u * (unsigned)(f * H + 8 * (v % VPF)));
+            // issued behind the compiler's back (see vm_wait): its wait-count pass would otherwise guard the first use of
+            // these registers, a tile later, with vmcnt(0) -- behind the 48 stores of this tile's phase B
+            raw[i] = gload16_hidden(reinterpret_cast<const char *>(a.x + tl * FT * H), 2u * (unsigned)(f * H + 8 * (v % VPF)));
         }
     };
     int64_t tile = blockIdx.x;
     if (tile < tiles) fetch(tile);
+    prologue_loads_done();
     for (; tile < tiles; tile += gridDim.x) {
         const int64_t n0 = tile * FT;
+        // the prefetched rows are older than the previous tile's 3 x 16 stores per wave (every tile but the tensor's last is
+        // full and stores unconditionally; that last one has no successor)
+        vm_wait<3 * 16>(raw);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = threadIdx.x + 384 * i, f = v / VPF, og = v % VPF;
@@ -605,18 +636,37 @@ __global__ __launch_bounds__(384, 2) void k_dec_p(DecArgs a, GroupOff go)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i *>(rowl + 32 * ks), wreg[c][ks], acc, 0, 0, 0);
-            if (col < a.M) {
-                char *yb = reinterpret_cast<char *>(a.y + n0 * a.M); // wave-uniform base of the tile's output rows
-                const unsigned yo = 4u * (unsigned)((32 * sub + 4 * h) * a.M + col);
+            // Stores without control flow around them on full tiles (all but the tensor's last): lanes of the ragged last
+            // column tile (col >= M) write to a sink word instead of being masked off.  Every conditional store would make
+            // the number of memory operations in flight unknowable to the compiler's wait-count pass, and the wait it
+            // then puts at the top of the next tile -- for the rows prefetched BEFORE these stores -- degenerates to
+            // vmcnt(0): every tile would begin by waiting for the previous tile's stores to be acknowledged.
+            const bool okc = col < a.M;
+            char *yl = okc ? reinterpret_cast<char *>(a.y + n0 * a.M) + 4u * (unsigned)((32 * sub + 4 * h) * a.M + col)
+                           : reinterpret_cast<char *>(as_global(&g_store_sink[l]));
+            const unsigned ystep = okc ? 4u * (unsigned)a.M : 0u;
+            if (n0 + FT <= a.N) {
+                char *yp = yl; // a running pointer: sixteen hoisted offsets per column tile would cost the kernel its occupancy
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { // frames (i & 3) + 8 * (i >> 2)
+                    const int32_t v = sat(asr(acc[i], rs), a.out_bits);
+                    *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), a.out_bits);
+                    yp += (i & 3) == 3 ? 5 * ystep : ystep;
+                }
+            } else {
+                char *yp = yl;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int fo = (i & 3) + 8 * (i >> 2);
                     if (nb + fo < a.N) {
                         const int32_t v = sat(asr(acc[i], rs), a.out_bits);
-                        *reinterpret_cast<int32_t *>(yb + yo + 4u * (unsigned)(fo * a.M)) = sat(wadd(v, bev[c]), a.out_bits);
+                        *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), a.out_bits);
                     }
+                    yp += (i & 3) == 3 ? 5 * ystep : ystep;
                 }
+                prologue_loads_done(); // the tensor's last tile: nothing is left in flight on this path
             }
+            __builtin_amdgcn_sched_barrier(0); // one column tile at a time: interleaved, the three of a wave do not fit its registers
         }
         __syncthreads(); // planes are single-buffered
     }

@@ -45,15 +45,70 @@ using i32x4 = __attribute__((ext_vector_type(4))) int;
 struct GroupOff {
     int64_t x, y, ws, status, state_in, state_out; // byte strides
 };
-template <class P> // P: any (possibly restrict-qualified) pointer type; a null pointer stays null
+// Every pointer a kernel receives is device memory.  The shift goes through an explicit GLOBAL (address space 1) pointer:
+// with integer arithmetic on the pointer value instead (ptrtoint / inttoptr), or with pointers that arrive inside a large
+// by-reference argument struct, the compiler cannot prove the address space and emits FLAT loads and stores -- which count
+// on lgkmcnt as well as vmcnt, so that every wait for LDS (each barrier of the tile kernels) also waits for the global
+// prefetches in flight.
+using gchar = __attribute__((address_space(1))) char;
+template <class P> // P: any (possibly restrict-qualified) pointer type
+__device__ __forceinline__ P as_global(P p)
+{
+    return (P)(char *)(gchar *)(char *)p;
+}
+template <class P> // a null pointer stays null
 __device__ __forceinline__ void gshift(P &p, int64_t bytes)
 {
-    if (p) p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+    p = p ? (P)(char *)((gchar *)(char *)p + bytes) : (P) nullptr;
 }
 template <class P> // for pointers that are never null
 __device__ __forceinline__ void gshift_nn(P &p, int64_t bytes)
 {
-    p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes);
+    p = (P)(char *)((gchar *)(char *)p + bytes);
+}
+
+// Placed in front of a tile loop: everything the prologue requested (the weights that stay in registers, the first tile)
+// has arrived.  Without it the compiler's wait-count pass has to assume, in EVERY iteration, that the prologue's loads
+// may still be pending at the first use of a weight register, and the wait it inserts there (vmcnt counts in order) also
+// waits for the newest loads in flight -- the next tile's prefetch, issued a few instructions earlier.
+__device__ __forceinline__ void prologue_loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); } // vmcnt(0) only
+
+// A 16-byte global load the compiler does not know to be a load (wave-uniform base + 32-bit byte offset), and the wait that
+// makes its result usable: at most NEWER memory operations of this wave issued after it may still be in flight (vmcnt
+// retires in order).  The registers pass through the wait statement, so nothing can be scheduled to read them above it.
+// For prefetches whose first use lies behind conditional or numerous stores: there the wait the compiler would insert by
+// itself is vmcnt(0).
+using v4i_ = __attribute__((ext_vector_type(4))) int;
+__device__ __forceinline__ v4i_ gload16_hidden(const char *base, unsigned off)
+{
+    v4i_ r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+__device__ __forceinline__ __attribute__((ext_vector_type(2))) int gload8_hidden(const char *base, unsigned off)
+{
+    __attribute__((ext_vector_type(2))) int r;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+template <int NEWER, class T, int N>
+__device__ __forceinline__ void vm_wait(T (&regs)[N])
+{
+    static_assert(NEWER >= 0 && NEWER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+    // volatile statements keep their order: every later reader of a register depends on its pass through here
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(regs[i]));
+}
+template <int NEWER, class T, int N, int M>
+__device__ __forceinline__ void vm_wait(T (&regs)[N][M])
+{
+    static_assert(NEWER >= 0 && NEWER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) asm volatile("" : "+v"(regs[i][j]));
 }
 
 // word index of (sequence b, step t, state p, component c) in a scan-native stream with TB blocks/sequence
