@@ -279,6 +279,7 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
  *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT, S5FXP_NO_COMPACT           unpacked gate epilogues / four-reduction BatchNorm exponents / no
  *                                                              live-state compaction
  *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
+ *   S5FXP_PLANE_SKEW=bytes                                     extra distance between the workspace's planes (multiple of 256)
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward
  * Results do not depend on any of them. */
 

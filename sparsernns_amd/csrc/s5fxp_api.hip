@@ -315,6 +315,7 @@ struct ModelCfg {
     bool no_pk16 = false;     // S5FXP_NO_PK16: unpacked epilogues in the gate kernel
     bool no_compact = false;  // S5FXP_NO_COMPACT: never run a layer on its live states only (s5fxp_fast.hpp FastLayer)
     int pairl_blocks = 32;    // S5FXP_PAIRL_BLOCKS=16: 16 time blocks per LDS buffer of the LDS-fed pair kernel
+    size_t plane_skew = 0;    // S5FXP_PLANE_SKEW=<bytes, multiple of 256>: extra distance between the workspace's planes (experiments)
     int64_t cap_enc = 512, cap_dec = 512, cap_cgate = 512, cap_bproj = 1024, cap_resid = 512; // S5FXP_WGS_*: workgroups per launch
     static ModelCfg from_env()
     {
@@ -328,6 +329,7 @@ struct ModelCfg {
         c.debug_sync = on("S5FXP_DEBUG_SYNC"); c.no_bn_ext = on("S5FXP_NO_BN_EXT"); c.no_pair = on("S5FXP_NO_PAIR");
         c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT");
         { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); c.pairl_blocks = e && std::atoi(e) == 16 ? 16 : 32; }
+        { const char *e = std::getenv("S5FXP_PLANE_SKEW"); c.plane_skew = e ? ((size_t)std::atoll(e) & ~(size_t)255) : 0; }
         c.cap_enc = cap("S5FXP_WGS_ENC", c.cap_enc); c.cap_dec = cap("S5FXP_WGS_DEC", c.cap_dec);
         c.cap_cgate = cap("S5FXP_WGS_CGATE", c.cap_cgate); c.cap_bproj = cap("S5FXP_WGS_BPROJ", c.cap_bproj);
         c.cap_resid = cap("S5FXP_WGS_RESID", c.cap_resid);

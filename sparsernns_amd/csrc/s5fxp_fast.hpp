@@ -224,8 +224,8 @@ FastWs fast_ws(const s5fxp_model *m, int B, int L)
     FastWs w{};
     w.TB = ((L + 3) / 4 + SCAN_DEPTH - 1) / SCAN_DEPTH * SCAN_DEPTH;
     size_t off = 0;
-    const size_t nh = al(N * m->H * 2 + 64); // int16 (+ slack for the 32-byte fragment loads of clamped tail lanes)
-    const size_t ns = al(((size_t)B * w.TB + SCAN_DEPTH) * m->P * 8 * 4);
+    const size_t nh = al(N * m->H * 2 + 64) + m->cfg.plane_skew; // int16 (+ slack for the 32-byte fragment loads of clamped tail lanes)
+    const size_t ns = al(((size_t)B * w.TB + SCAN_DEPTH) * m->P * 8 * 4) + m->cfg.plane_skew;
     w.hA = off; off += nh;
     w.hB = off; off += nh;
     w.x1 = off; off += nh;
