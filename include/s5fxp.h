@@ -278,6 +278,7 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
  *   S5FXP_NO_PAIR, S5FXP_PAIR_GLOBAL, S5FXP_PAIRL_BLOCKS=16   recurrence kernel choice (see s5fxp_model_recurrence_kernel)
  *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT, S5FXP_NO_COMPACT           unpacked gate epilogues / four-reduction BatchNorm exponents / no
  *                                                              live-state compaction
+ *   S5FXP_NO_DEC_RESID                                         the last layer's residual pass as a launch of its own
  *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
  *   S5FXP_PLANE_SKEW=bytes                                     extra distance between the workspace's planes (multiple of 256)
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward

@@ -551,12 +551,26 @@ __device__ int32_t g_store_sink[64];
 // store instruction writes 128 contiguous bytes of one output row per half wave.
 // LDS: [X hi][X lo]
 // ---------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
+// RESID: the last layer's residual pass (mfma_bn.hpp k_resid_minmax16 without its extremes, which nobody needs after the
+// last layer) happens here, on the way in: a.x is the layer's INPUT (skip), rz.z the gate kernel's output, and
+// h = relu(z + skip) (fxpmodel.py:1147-1159) is formed in registers -- the h plane is neither written nor read back
+// (-75 + 25 MB per batch at configs[1]) and the forward is one launch shorter.  The residual exponents come from the
+// maxima the gate kernel left, derived by every workgroup for itself as in the B projection.
+struct DecResid {
+    const int16_t *z;
+    ResidHead hd;
+    int32_t res_bits, skip_bits;
+};
+template <int KS, bool RESID = false>
+__global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, DecResid rz, GroupOff go)
 {
     {
         const int64_t g = blockIdx.y;
         gshift(a.x, g * go.ws); gshift(a.y, g * go.y); gshift(a.xe.dyn, g * go.ws); gshift(a.status, g * go.status);
+        if constexpr (RESID) {
+            gshift(rz.z, g * go.ws); gshift_nn(rz.hd.d, g * go.ws); gshift(rz.hd.skip_e.dyn, g * go.ws);
+            gshift_nn(rz.hd.status_exps, g * go.status);
+        }
     }
     constexpr int H = 32 * KS, FT = 64, KP = H + 16, NW = 6, CT = 9, CPW = 3;
     constexpr int VPF = H / 8, NV = FT * VPF / 384;
@@ -566,7 +580,24 @@ __global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int sub = wave / 3, c0 = wave % 3;
     const int64_t tiles = (a.N + FT - 1) / FT;
-    const int xe0 = a.xe.get();
+    AddCb rp{};
+    if constexpr (RESID) {
+        __shared__ AddCb sp;
+        if (rz.hd.enable) {
+            if (threadIdx.x == 0) {
+                sp = finalize_add_cb(rz.hd.d->mx + (rz.hd.d->redo ? rz.hd.redo_slot : 8), rz.hd.res_exp, rz.hd.skip_e.get(), rz.res_bits, a.status);
+                if (blockIdx.x == 0) {
+                    rz.hd.d->res = sp;
+                    rz.hd.status_exps[4] = sp.eo;
+                }
+            }
+            __syncthreads();
+            rp = sp;
+        } else {
+            rp = rz.hd.d->res;
+        }
+    }
+    const int xe0 = RESID ? rp.eo : a.xe.get();
     const bool conv = a.xb > a.inp_bits || xe0 > a.inp_exp;
     int rs = (conv ? a.inp_exp : xe0) + a.w_exp - a.out_exp;
     if (rs < 0 || rs > 31) {
@@ -585,7 +616,7 @@ __global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
         for (int ks = 0; ks < KS; ++ks)
             wreg[c][ks] = *reinterpret_cast<const v4i *>(a.w.wt + (size_t)col * a.w.Kp + 32 * ks + 16 * h);
     }
-    v4i raw[NV];
+    v4i raw[NV], rawz[RESID ? NV : 1];
     auto fetch = [&](int64_t tl) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -593,6 +624,8 @@ __global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
             const int64_t left = a.N - tl * FT; // frames from the tile's first to the end of the tensor (wave-uniform)
             int f = v / VPF;
             f = f < left ? f : (int)left - 1;
+            if constexpr (RESID)
+                rawz[i] = gload16_hidden(reinterpret_cast<const char *>(rz.z + tl * FT * H), 2u * (unsigned)(f * H + 8 * (v % VPF)));
             // issued behind the compiler's back (see vm_wait): its wait-count pass would otherwise guard the first use of
             // these registers, a tile later, with vmcnt(0) -- behind the 48 stores of this tile's phase B
             raw[i] = gload16_hidden(reinterpret_cast<const char *>(a.x + tl * FT * H), 2u * (unsigned)(f * H + 8 * (v % VPF)));
@@ -606,11 +639,21 @@ __global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, GroupOff go)
         // the prefetched rows are older than the previous tile's 3 x 16 stores per wave (every tile but the tensor's last is
         // full and stores unconditionally; that last one has no successor)
         vm_wait<3 * 16>(raw);
+        if constexpr (RESID) vm_wait<3 * 16>(rawz);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = threadIdx.x + 384 * i, f = v / VPF, og = v % VPF;
             int32_t x[8];
             unpack8_i16(raw[i], x);
+            if constexpr (RESID) {
+                int32_t z[8];
+                unpack8_i16(rawz[i], z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int32_t rr = add_cb_apply(z[e], rz.res_bits, x[e], rz.skip_bits, rp, rz.res_bits);
+                    x[e] = rr < 0 ? 0 : rr;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = cv(x[e]);
             v2i hi, lo;

@@ -434,6 +434,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     // (mfma_bn.hpp k_resid_minmax16); with a multi-rank hook the maxima are exchanged in between, so they stay
     const bool fold = bn_ext && !allreduce;
 
+    bool dec_resid = false; // the decoder does the last layer's residual pass itself
+    DecResid dz{};
+    int dec_bits = 0;
     for (int li = 0; li < m->n_layers; ++li) {
         const LayerDev &l = m->layers[li];
         const FastLayer &fl = F.layers[li];
@@ -714,6 +717,16 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const int redo_slot = (allreduce || defer) ? 8 : 11; // mode A moved them; deferred: no re-run happened
         if (!fold)
             hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps, redo_slot);
+        const bool more_layers = li + 1 < m->n_layers;
+        if (bn_ext && fold && !tr && !more_layers && !cfg.no_dec_resid && !big) { // (dim 1.0: the fused decoder does not fit its registers)
+            // the last layer's residual pass rides on the decoder (proj_p.hpp k_dec_p<.., RESID>)
+            dec_resid = true;
+            dz.z = I16(w.z); dz.res_bits = l.res_bits; dz.skip_bits = hb;
+            dz.hd.d = d; dz.hd.res_exp = l.res_exp; dz.hd.skip_e = he; dz.hd.redo_slot = redo_slot; dz.hd.status_exps = st_exps;
+            dz.hd.enable = 1;
+            dec_bits = l.res_bits;
+            break;
+        }
         if (bn_ext) {
             const bool more = li + 1 < m->n_layers;
             float *ext_next = more ? reinterpret_cast<float *>(ws + w.ext) + (size_t)(li + 1) * 2 * H * EXT_REPS : nullptr;
@@ -738,11 +751,20 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const DenseDev &e = m->dec;
         DecArgs a{};
         a.x = h; a.y = y; a.w = F.dec.w; a.bias_eff = F.dec.bias_eff; a.N = N; a.H = H; a.M = e.M;
-        a.xb = hb; a.xe = he; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.w_exp = e.w_exp;
+        a.xb = dec_resid ? dec_bits : hb; a.xe = he; a.inp_bits = e.inp_bits; a.inp_exp = e.inp_exp; a.w_exp = e.w_exp;
         a.out_bits = e.out_bits; a.out_exp = e.out_exp; a.status = status;
         const size_t smem = 2 * 64 * (size_t)(H + 16);
-        if (big) launch6(k_dec_p<6>, smem, a);
-        else launch6(k_dec_p<3>, smem, a);
+        auto launch_dec = [&](auto kernel) {
+            if (smem > 65536)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(kernel, dim3(grid_dec, G), dim3(384), smem, st, a, dz, go);
+        };
+        if (dec_resid) {
+            launch_dec(k_dec_p<3, true>);
+        } else {
+            if (big) launch_dec(k_dec_p<6, false>);
+            else launch_dec(k_dec_p<3, false>);
+        }
         if (!stage_ok("decoder", -1)) return S5FXP_EHIP;
     }
     return launch_rc();
