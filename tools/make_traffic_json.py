@@ -28,7 +28,8 @@ doc = dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passe
 for g in (1, 8):
     f, w = read(f"{prefix}_pmc_fetch_g{g}.txt", "FETCH_SIZE"), read(f"{prefix}_pmc_write_g{g}.txt", "WRITE_SIZE")
     per = {k: int(round((2 * f[k] + w[k]) * 1000)) for k in KERNELS if k in f and k in w}
-    fwd = per["k_enc_p"] + 3 * (per["k_bproj_p"] + per["k_scan_pairl_asm"] + per["k_cgate_p"] + per["k_resid_minmax16"]) + per["k_dec_p"]
+    # three layers; the last one's residual pass is part of the decoder (proj_p.hpp k_dec_p<.., RESID>): two launches of k_resid_minmax16
+    fwd = per["k_enc_p"] + 3 * (per["k_bproj_p"] + per["k_scan_pairl_asm"] + per["k_cgate_p"]) + 2 * per["k_resid_minmax16"] + per["k_dec_p"]
     doc["entries"].append(dict(batches_per_launch=g, traffic_bytes_per_launch=per, per_launch_set=fwd, per_batch=fwd // g,
                                FETCH_SIZE_KB=f, WRITE_SIZE_KB=w))
 json.dump(doc, open(out, "w"), indent=1)
