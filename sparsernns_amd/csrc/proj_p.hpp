@@ -562,7 +562,7 @@ struct DecResid {
     int32_t res_bits, skip_bits;
 };
 template <int KS, bool RESID = false>
-__global__ __launch_bounds__(384, 3) void k_dec_p(DecArgs a, DecResid rz, GroupOff go)
+__global__ __launch_bounds__(384, KS == 6 && RESID ? 2 : 3) void k_dec_p(DecArgs a, DecResid rz, GroupOff go)
 {
     {
         const int64_t g = blockIdx.y;

@@ -718,7 +718,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (!fold)
             hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(64), 0, st, d, l.res_exp, he, l.res_bits, status, st_exps, redo_slot);
         const bool more_layers = li + 1 < m->n_layers;
-        if (bn_ext && fold && !tr && !more_layers && !cfg.no_dec_resid && !big) { // (dim 1.0: the fused decoder does not fit its registers)
+        if (bn_ext && fold && !tr && !more_layers && !cfg.no_dec_resid) {
             // the last layer's residual pass rides on the decoder (proj_p.hpp k_dec_p<.., RESID>)
             dec_resid = true;
             dz.z = I16(w.z); dz.res_bits = l.res_bits; dz.skip_bits = hb;
@@ -760,7 +760,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             hipLaunchKernelGGL(kernel, dim3(grid_dec, G), dim3(384), smem, st, a, dz, go);
         };
         if (dec_resid) {
-            launch_dec(k_dec_p<3, true>);
+            if (big) launch_dec(k_dec_p<6, true>); // 192 channels: 2 x 4 vectors of prefetch, one workgroup per CU
+            else launch_dec(k_dec_p<3, true>);
         } else {
             if (big) launch_dec(k_dec_p<6, false>);
             else launch_dec(k_dec_p<3, false>);
