@@ -501,6 +501,15 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
             const int sub = sub0 + u * SUBSTEP;
             const int64_t n = n0 + 32 * sub + r;
             v16i acc;
+#ifdef S5_GATE_CHECK
+            bool live2 = false; // out2's operand: one decision for the whole row of fragments (mfma_planes takes them all)
+#pragma unroll
+            for (int ks = 0; ks < NT; ++ks) live2 |= gate_check<2>(Xl + (32 * sub + r) * KPX + 16 * h + 32 * ks, -(FT * KPX), 2);
+            if (!live2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0;
+            } else
+#endif
             mfma_planes<NT>(acc, wo2, Xh + (32 * sub + r) * KPX + 16 * h, Xl + (32 * sub + r) * KPX + 16 * h, cs2 + ch0);
             auto b2_pk16 = [&]() {
                 // out2 bias, table sigmoid, gate (fxpmodel.py:1133-1137, :97-144, :1075-1093) on int16 pairs

@@ -336,10 +336,47 @@ __device__ __forceinline__ void mfma_planes(v16i &acc, const v4i (&w)[KSTEPS], c
 // the same for NPL byte planes [plane][frame][k] (plane NPL-1 = signed top byte), Horner from the top: the constant
 // 128*sum(w) enters at every shift, so after NPL-1 shifts it has the weight 2^(8(NPL-2)) + ... + 2^8 + 1 that the
 // +128 offsets of the lower planes need
+#ifdef S5_GATE_CHECK
+// EXPERIMENT builds only (tools/variant.py): the test an activation-gating kernel makes before each
+// MFMA of the gate kernel's two projections -- is this wave's operand fragment (32 frames x 32 k, every byte plane) all zero?
+//   -DS5_GATE_CHECK=1 (gate_count): counts them; the MFMA still runs.  [0]/[1]: fragments / all-zero fragments of the C
+//     projection's operand (the states after the complex ReLU, fxpmodel.py:740-742), [2]/[3]: the same for out2's operand (the
+//     SSM output after the ReLU, :1125).  Not for timing: every wave hits the same two counters.
+//   -DS5_GATE_CHECK=2 (gate_skip): branches around the MFMAs of an all-zero fragment, no counters: what a gating kernel
+//     costs.  (Skipping drops the fragment's share of the lower planes' +128 correction: exact only when nothing is skipped
+//     or the skipped k carry zero weights, as the padding slots of a compacted layer do.)
+__device__ unsigned long long g_gate_frag[4];
+template <int NPL>
+__device__ __forceinline__ bool gate_check(const int8_t *frag0, int plane_stride, int slot)
+{
+    unsigned nz = 0;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        const v4i b = *reinterpret_cast<const v4i *>(frag0 + pl * plane_stride);
+        const unsigned pat = pl == NPL - 1 ? 0u : 0x80808080u; // the lower planes hold (byte ^ 0x80)
+        nz |= ((unsigned)b[0] ^ pat) | ((unsigned)b[1] ^ pat) | ((unsigned)b[2] ^ pat) | ((unsigned)b[3] ^ pat);
+    }
+    const bool any = __any(nz != 0);
+#if S5_GATE_CHECK == 1
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_gate_frag[slot], 1ull);
+        if (!any) atomicAdd(&g_gate_frag[slot + 1], 1ull);
+    }
+    return true;
+#else
+    return any;
+#endif
+}
+#endif
 template <int KSTEPS, int NPL>
 __device__ __forceinline__ void mfma_nplanes(v16i &acc, const v4i (&w)[KSTEPS], const int8_t *row0, int plane_stride,
                                              const int32_t *cs)
 {
+#ifdef S5_GATE_CHECK
+    bool live[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) live[ks] = gate_check<NPL>(row0 + 32 * ks, plane_stride, 0);
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0;
 #pragma unroll
@@ -353,8 +390,12 @@ __device__ __forceinline__ void mfma_nplanes(v16i &acc, const v4i (&w)[KSTEPS], 
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#ifdef S5_GATE_CHECK
+            if (!live[ks]) continue;
+#endif
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[ks], *reinterpret_cast<const v4i *>(row0 + pl * plane_stride + 32 * ks), acc, 0, 0, 0);
+        }
     }
 }
 

@@ -961,3 +961,16 @@ extern "C" int s5fxp_debug_phase_prof(long long *host_out, int n)
     return hip_rc(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase_prof), (size_t)n * sizeof(long long)));
 }
 #endif
+
+#ifdef S5_GATE_CHECK
+// experiment builds only (proj_p.hpp gate_check): reads (and optionally clears) the fragment counters
+extern "C" int s5fxp_debug_gate_counts(unsigned long long out[4], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(s5::g_gate_frag), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(s5::g_gate_frag), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -1073,6 +1073,35 @@ def test_layers_run_on_their_live_states_only(ds, monkeypatch):
     assert slots(eng2) == [P] * nl and np.array_equal(y2.numpy(), ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ds,B,L", [(0.5, 3, 333), (0.5, 2, 64), (1.0, 2, 129), (0.5, 33, 1)])
+def test_decoder_carries_the_last_residual_pass(ds, B, L, monkeypatch):
+    """The fused path's decoder forms the last layer's h = relu(z + skip) itself (proj_p.hpp k_dec_p<.., RESID>) and derives
+    the residual exponent in its own prologue: the output and the reported ``residadd`` exponents must be the oracle's, on full
+    tiles, a ragged last tile (N % 64 != 0) and a single frame, and an engine created with S5FXP_NO_DEC_RESID (the residual
+    pass as its own launch) must give the same bits."""
+    from sparsernns_amd.fxparray import FxpArray
+    from sparsernns_amd.fxpmodel import build_regression_model
+
+    md, qc, dims = _make(dict(dim_scale=ds, calib_L=256, state_headroom_bits=1))
+    model = build_regression_model(md, qc, dims["n_layers"])
+    cm = cref.CModel(model.export())
+    fx = _input(qc, dims, B, L, seed=5)
+    ref, rb, re_, rtr = cm.forward(fx.data, fx.bits, fx.exp, trace=True)
+    eng = model.engine()
+    y = eng.forward(FxpArray(fx.data, fx.bits, fx.exp))
+    _ran_fused(eng, dims["n_layers"])
+    assert (y.bits, y.exp) == (rb, re_) and np.array_equal(y.numpy(), ref)
+    got = [e["residadd"] for e in eng.layer_exponents()]
+    assert got == [t["residadd_exp"] for t in rtr]
+    monkeypatch.setenv("S5FXP_NO_DEC_RESID", "1")
+    eng2 = build_regression_model(md, qc, dims["n_layers"]).engine()
+    monkeypatch.delenv("S5FXP_NO_DEC_RESID")
+    y2 = eng2.forward(FxpArray(fx.data, fx.bits, fx.exp))
+    assert np.array_equal(y2.numpy(), ref)
+    assert got == [e["residadd"] for e in eng2.layer_exponents()]
+
+
 @pytest.mark.parametrize("case", ["tiny_bnsb", "ndns05"])
 def test_layer_forward_entry_point_matches_the_oracle_layer_by_layer(case):
     """s5fxp_layer_forward (FxpSequenceLayer.forward, fxpmodel.py:1110-1161): feeding the oracle's
