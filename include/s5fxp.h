@@ -203,8 +203,8 @@ size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L);
  *   [8 + 8*l + 0..4] layer l: exponents chosen by the 4 BatchNorm ops and the residual add,
  *   [8 + 8*l + 5]    layer l: the recurrence kernel that was enqueued first, coded as s5fxp_model_recurrence_kernel
  *                    (5 = the exact 32-bit quad chain of a S5FXP_FWD_EXACT forward),
- *   [8 + 8*l + 6]    layer l: the state slots its kernels ran on: P, or P / 2 when the layer was compacted to its live
- *                    states (s5fxp_model_live_states). */
+ *   [8 + 8*l + 6]    layer l: the state slots its kernels ran on: P, or the live states rounded up to a multiple of 32
+ *                    when the layer was compacted (s5fxp_model_live_states). */
 #define S5FXP_STATUS_WORDS 128
 enum { S5FXP_PATH_GENERIC = 1, S5FXP_PATH_FUSED = 2 };
 enum {
@@ -297,7 +297,8 @@ int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_t *x, int x
 int s5fxp_model_layer_out_bits(const s5fxp_model *m, int layer);
 /* States of `layer` whose rows of B_bar are not all zero.  The others receive Bu = 0 at every step and stay (0, 0) from a
  * zero carry (fxpmodel.py:147-172), so their columns of C multiply zeros: when at most P / 2 states are live, forwards on
- * the fused path that neither trace the states nor carry them in or out run the layer's kernels on P / 2 state slots
+ * the fused path that neither trace the states nor carry them in or out run the layer's kernels on the fewest groups of 32
+ * state slots that hold the live ones (32 or 64 of 128, 32 of 64)
  * (bit-identical; S5FXP_NO_COMPACT at model creation switches it off).  -1: bad argument. */
 int s5fxp_model_live_states(const s5fxp_model *m, int layer);
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
 // stream (pair16-native), one 8-byte item per producer lane
 // NC: 32-column tiles of [B_re | B_im] (= 2P / 32).  NC == NT: one tile per wave, both 32-frame halves of the tile's 64
 // frames; NC == NT / 2 (a layer compacted to its live states, s5fxp_fast.hpp): wave w takes column tile w % NC and the ONE
-// half w / NC -- the workgroup keeps its size, so phase A (the bulk of the kernel) is unchanged.
+// half w / NC -- the workgroup keeps its size, so phase A (the bulk of the kernel) is unchanged; NC == NT / 4 (a 128-state
+// layer on 32 slots): the same, and the waves with w / NC >= 2 sit phase B out.
 template <int KS, int NT, bool TRACE, int SM = 0, int NC = NT>
 __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff go)
 {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
         gshift(a.bn.dyn, g * go.ws); gshift(a.bn.xe.dyn, g * go.ws); gshift(a.x, g * go.ws); gshift(a.bq, g * go.ws); gshift(a.u, g * go.ws);
         gshift(a.ext, g * go.ws); gshift(a.status, g * go.status); gshift(a.status_exps, g * go.status);
     }
-    static_assert(NC == NT || 2 * NC == NT, "column tiles per workgroup");
+    static_assert(NC == NT || 2 * NC == NT || 4 * NC == NT, "column tiles per workgroup");
     constexpr int H = 32 * KS, FT = 64, KP = 32 * KS + 16, PC = 16 * NC, SUB0_STEP = NT / NC; // halves a wave takes: 2 / SUB0_STEP
     constexpr int VPF = H / 8;             // 16-byte vectors per frame
     constexpr int NTHR = 64 * NT;          // one wave per column tile: 256 threads at dim 0.5, 512 at dim 1.0
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
 #pragma unroll
             for (int sub0 = 0; sub0 < 2; sub0 += SUB0_STEP) {
                 const int sub = sub0 + wsub;
+                if (SUB0_STEP > 2 && sub >= 2) break; // a quarter of the column tiles: half of the waves have no unit in phase B
                 const int8_t *rowh = xh + (32 * sub + r) * KP + 16 * h, *rowl = xl + (32 * sub + r) * KP + 16 * h;
                 v16i acc;
 #ifdef S5_BPROJ_CSR

@@ -21,15 +21,16 @@ struct FastLayer {
     // rounds the rows of slow states away: 43-46 of 64 on the N-DNS recipe at dim_scale 0.5, profiles/r03_sparsity_census.log)
     // receives Bu = 0 at every step, so from a zero carry it stays (0, 0) for ever: asr(A * 0) = 0, the complex ReLU keeps
     // (0, 0), and its column of C multiplies zeros (fxpmodel.py:147-172, :740-763).  When at most half of a layer's states
-    // are live, the layer is ALSO packed over P / 2 state slots -- the live states in their order, then zero slots -- and
+    // are live, the layer is ALSO packed over c_slots state slots -- the live states in their order, then zero slots -- and
     // forwards that neither trace the states nor carry them in or out run every kernel of the layer on that half: half the
     // bytes of both recurrence streams, half the recurrence waves, half the gate kernel's phase A.  Bit-identical by the
     // argument above (the dropped terms are exact zeros of int32 sums).
     bool compact_ok = false;
     int n_live = 0;
+    int c_slots = 0; // state slots of the compacted layer: n_live rounded up to a multiple of 32 (when that is <= P / 2)
     MfmaWDev c_bproj, c_bproj_pair, c_cre, c_cim;
     ScanBounds c_bounds; // the recurrence kernels' exactness bounds over the live states only
-    const int32_t *c_a_re = nullptr, *c_a_im = nullptr; // (P / 2) Lambda_bar of the slots (0 for the empty ones)
+    const int32_t *c_a_re = nullptr, *c_a_im = nullptr; // (c_slots) Lambda_bar of the slots (0 for the empty ones)
 };
 
 struct FastModel {
@@ -153,8 +154,10 @@ void pack_fast(Packer &p, const s5fxp_model_desc *d, FastModel *f)
                 if (live) idx.push_back(q);
             }
             o.n_live = (int)idx.size();
-            const int Pc = P / 2;
-            o.compact_ok = Pc % 32 == 0 && o.n_live <= Pc;
+            // the fewest 32-state groups that hold the live states, if that is at most half of the layer's
+            const int Pc = o.n_live <= 32 ? 32 : (o.n_live + 31) / 32 * 32;
+            o.compact_ok = P % 64 == 0 && Pc <= P / 2;
+            o.c_slots = o.compact_ok ? Pc : P;
             if (o.compact_ok) {
                 o.c_bounds = scan_bounds(s, idx.data(), o.n_live, Pc, true);
                 idx.resize(Pc, -1);
@@ -353,7 +356,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     for (int li = 0; li < m->n_layers; ++li) {
         const bool compact = F.layers[li].compact_ok && !cfg.no_compact && !traces && !state_in && !state_out;
         si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr, compact).code;
-        si.slots[li] = compact ? m->P / 2 : m->P;
+        si.slots[li] = compact ? F.layers[li].c_slots : m->P;
     }
     hipLaunchKernelGGL(k_clear2, dim3(8, G), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
                        (int)(w.dyn_bytes / 4), si, m->n_layers, go);
@@ -482,12 +485,12 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
 
         // ---- B projection -> scan-native stream (+ u for the C projection)
         const int sh_re = s.Bu_re_exp - s.x_re_exp, sh_im = s.Bu_im_exp - s.x_im_exp;
-        // live-state compaction (FastLayer): this layer's kernels run on P / 2 state slots
+        // live-state compaction (FastLayer): this layer's kernels run on c_slots state slots
         const bool compact = fl.compact_ok && !cfg.no_compact && !tr && !state_in && !state_out;
         const Rung rung = select_rung(m, li, fwd_flags, tr != nullptr, compact);
         const bool quad = rung.quad, s16 = rung.s16, pair = rung.pair, pairl = rung.pairl;
         const int32_t l_pair_xmax = compact ? fl.c_bounds.pair_xmax : l.pair_xmax, l_quad_xmax = compact ? fl.c_bounds.quad_xmax : l.quad_xmax;
-        const int P = compact ? m->P / 2 : m->P;
+        const int P = compact ? fl.c_slots : m->P;
         const int32_t *la_re = compact ? fl.c_a_re : l.a_re, *la_im = compact ? fl.c_a_im : l.a_im;
         const MfmaW &w_bproj = compact ? fl.c_bproj.w : fl.bproj.w, &w_bproj_pair = compact ? fl.c_bproj_pair.w : fl.bproj_pair.w;
         const MfmaW &w_cre = compact ? fl.c_cre.w : fl.cre.w, &w_cim = compact ? fl.c_cim.w : fl.cim.w;
@@ -519,7 +522,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                 auto bproj = [&](auto sm) {
                     constexpr int SM = decltype(sm)::value;
                     if (big) {
-                        if (compact) launch_smem(k_bproj_p<6, 8, false, SM, 4>, pgrid, smem, st, a, bthr, G, go);
+                        if (compact && P == 32) launch_smem(k_bproj_p<6, 8, false, SM, 2>, pgrid, smem, st, a, bthr, G, go);
+                        else if (compact) launch_smem(k_bproj_p<6, 8, false, SM, 4>, pgrid, smem, st, a, bthr, G, go);
                         else launch_smem(k_bproj_p<6, 8, false, SM, 8>, pgrid, smem, st, a, bthr, G, go);
                     } else {
                         if (compact) launch_smem(k_bproj_p<3, 4, false, SM, 2>, pgrid, smem, st, a, bthr, G, go);
@@ -651,7 +655,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                         constexpr bool S16_ = decltype(s16_t)::value, DIR_ = decltype(direct_t)::value, PAIR_ = decltype(pair_t)::value,
                                        PK_ = decltype(pk16_t)::value;
                         if (big) {
-                            if (compact) launch6g(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            if (compact && P == 32) launch6g(k_cgate_p<1, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            else if (compact) launch6g(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                             else launch6g(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                         } else {
                             if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
@@ -693,7 +698,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     if (big) launch6g(k_cgate_p<4, 6, true, false, false, 64, true>, cgw, smem_w, e, 768);
                     else launch6g(k_cgate_p<2, 3, true, false, false, 64, true>, cgw, smem_w, e);
                 } else if (big) {
-                    if (compact) launch6g(k_cgate_p<2, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
+                    if (compact && P == 32) launch6g(k_cgate_p<1, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
+                    else if (compact) launch6g(k_cgate_p<2, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
                     else launch6g(k_cgate_p<4, 6, false, false, false, 64, true>, cgw, smem_w, e, 768);
                 } else {
                     if (compact) launch6g(k_cgate_p<1, 3, false, false, false, 64, true>, cgw, smem_w, e);
