@@ -42,7 +42,7 @@ def pmc_traffic(B, L, P, kernel, groups, slots):
         return None
     with open(p) as f:
         t = json.load(f)
-    if (t["B"], t["L"], t["P"]) != (B, L, P) or list(t["state_slots"]) != list(slots):
+    if (t["B"], t["L"], t["P"]) != (B, L, P) or list(t.get("stream_slots", t.get("state_slots", []))) != list(slots):
         return None
     for e in t["entries"]:
         if e["batches_per_launch"] == groups and kernel in e["traffic_bytes_per_launch"]:
@@ -380,8 +380,11 @@ def main() -> None:
     # [8 + 8l + 6] of the last forward says how many (the algorithmic bytes stay 16 * P: the dead states are part of the model)
     stw = eng.lane_status(lanes_of(1)[0]).cpu().numpy()
     slots = [int(stw[8 + 8 * i + 6]) or dims["P"] for i in range(nl)]
-    stored = scan_stored_bytes(scan_kernel, algo_bytes) * sum(slots) // (nl * dims["P"])
-    traffic = pmc_traffic(B, L, dims["P"], scan_kernel, 1, slots)
+    # ... and word [8 + 8l + 7] how many of those slots the two recurrence streams hold (the LDS-fed pair kernel on a layer
+    # compacted to 32 slots stores and loads only the live ones): that is what the kernel moves
+    stream_slots = [int(stw[8 + 8 * i + 7]) or slots[i] for i in range(nl)]
+    stored = scan_stored_bytes(scan_kernel, algo_bytes) * sum(stream_slots) // (nl * dims["P"])
+    traffic = pmc_traffic(B, L, dims["P"], scan_kernel, 1, stream_slots)
     moved = traffic if traffic is not None else stored
     def roof(bytes_algo, bytes_moved, seconds):
         """SURVEY.md 8(d): `frac` is quoted on the ALGORITHMIC bytes (16*P per frame, the reference's int32 element type);
@@ -400,7 +403,7 @@ def main() -> None:
                     stream_width="int32 arithmetic; " + ("int16 range-guarded streams (Bu in, states out): every stored state is checked against the "
                                                          "kernel's exactness bound by its consumer" if stored < algo_bytes else "int32 streams"),
                     moved_bytes_source="PMC (profiles/r03_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "stream sizes",
-                    launch=f"one reference batch per launch (B={B}), one launch at a time", state_slots_per_layer=slots,
+                    launch=f"one reference batch per launch (B={B}), one launch at a time", state_slots_per_layer=slots, stream_slots_per_layer=stream_slots,
                     measured="HIP start/stop events attached to the launch (hipExtLaunchKernelGGL), one layer per launch set",
                     avg_kernel_us_in_the_timed_region=round(scan_inflight_s * 1e6, 2), batches_per_launch_in_the_timed_region=G)
     if ev1 is not None and G > 1:
@@ -408,7 +411,7 @@ def main() -> None:
         # bytes are G x 16 P B L; it moves a quarter to a half of them, so its fraction is quoted on the moved bytes: roof()).  The
         # plain one-batch launch -- a latency chain on B * P / 32 workgroups, the launch SURVEY.md 8(d) and the north star's
         # "40 % on the scan kernel" speak of -- stays beside it.
-        tg = pmc_traffic(B, L, dims["P"], scan_kernel, G, slots)
+        tg = pmc_traffic(B, L, dims["P"], scan_kernel, G, stream_slots)
         one = {k: roofline[k] for k in ("achieved", "frac", "frac_basis", "frac_algorithmic", "frac_moved", "avg_kernel_us", "traffic",
                                         "algorithmic_bytes_per_launch", "moved_bytes_per_launch", "launch")}
         roofline.update(roof(G * algo_bytes, tg if tg is not None else G * stored, scan_avg(ev1)))

@@ -204,7 +204,9 @@ size_t s5fxp_workspace_bytes(const s5fxp_model *m, int B, int L);
  *   [8 + 8*l + 5]    layer l: the recurrence kernel that was enqueued first, coded as s5fxp_model_recurrence_kernel
  *                    (5 = the exact 32-bit quad chain of a S5FXP_FWD_EXACT forward),
  *   [8 + 8*l + 6]    layer l: the state slots its kernels ran on: P, or the live states rounded up to a multiple of 32
- *                    when the layer was compacted (s5fxp_model_live_states). */
+ *                    when the layer was compacted (s5fxp_model_live_states).
+ *   [8 + 8*l + 7]    layer l: the state slots its two recurrence streams hold: [8 + 8*l + 6], or fewer -- the live states
+ *                    rounded up to an even number -- when the LDS-fed pair kernel runs a layer compacted to 32 slots. */
 #define S5FXP_STATUS_WORDS 128
 enum { S5FXP_PATH_GENERIC = 1, S5FXP_PATH_FUSED = 2 };
 enum {
@@ -279,6 +281,7 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
  *   S5FXP_NO_PK16, S5FXP_NO_BN_EXT, S5FXP_NO_COMPACT           unpacked gate epilogues / four-reduction BatchNorm exponents / no
  *                                                              live-state compaction
  *   S5FXP_NO_DEC_RESID                                         the last layer's residual pass as a launch of its own
+ *   S5FXP_NO_LIVE_LANES                                        a compacted layer's recurrence streams keep their padding slots
  *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
  *   S5FXP_PLANE_SKEW=bytes                                     extra distance between the workspace's planes (multiple of 256)
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward

@@ -24,6 +24,7 @@ struct StatusInit {
     int32_t path;
     int32_t rk[15];    // 8 + 8 * n_layers <= S5FXP_STATUS_WORDS
     int32_t slots[15];
+    int32_t stream[15]; // [8 + 8l + 7]: state slots the recurrence streams hold (<= slots)
 };
 __global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, int nb, StatusInit si, int n_layers, GroupOff go)
 {
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void k_clear2(int32_t *a, int na, int32_t *b, 
             if (i == 2) v = si.path;
             else if (i >= 8 && (i & 7) == 5 && (i - 8) / 8 < n_layers) v = si.rk[(i - 8) / 8];
             else if (i >= 8 && (i & 7) == 6 && (i - 8) / 8 < n_layers) v = si.slots[(i - 8) / 8];
+            else if (i >= 8 && (i & 7) == 7 && (i - 8) / 8 < n_layers) v = si.stream[(i - 8) / 8];
             a[i] = v;
         } else b[i - na] = 0;
     }
@@ -433,6 +435,7 @@ struct BprojM2Args {
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
     int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
     int32_t k_re;        // SM = 2 (pair-native K stream): 2^16 - 2^(16 - A_re_exp), the addend of the negated product
+    int32_t live_slots;  // SM = 3, > 0: only state slots below it are stored (scan_quad.hpp ScanPairLArgs::live_lanes)
     // != nullptr: the per-channel extremes of the layer input (ext_reps replicas of 2H floats); every workgroup derives the
     // BatchNorm exponents from them in its prologue (bn_finalize_mm_body), workgroup 0 publishes them
     const float *ext;

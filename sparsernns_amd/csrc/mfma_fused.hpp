@@ -33,6 +33,7 @@ struct CGateArgs {
     LayerDyn *dynw;
     int32_t *status;
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
+    int32_t live_slots; // PAIR, > 0: state slots at or above it are zero and not in the stream (scan_quad.hpp ScanPairLArgs)
     int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
     const int32_t *sigtab; // [2][7 << sig_x]: gate operand r for a non-positive / positive sigmoid input (k_cgate_p)
     const int32_t *run_if; // WIDE (exact re-run): do the work only when *run_if != 0 (nullptr: always)
@@ -307,8 +308,11 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                 int o = 4 * grp;
                 if (o >= nv) o = (nv - 1) & ~3;
                 const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
-                xq[i][0] = gload8_hidden(xb, xo);
-                xq[i][1] = gload8_hidden(xb, xo + 16);
+                xq[i][0] = xq[i][1] = v2i{0, 0};
+                if (a.live_slots <= 0 || p < a.live_slots) {
+                    xq[i][0] = gload8_hidden(xb, xo);
+                    xq[i][1] = gload8_hidden(xb, xo + 16);
+                }
             }
         }
     };
@@ -376,7 +380,10 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                         } else {
                             const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b0, t0 >> 3, 0, a.TB >> 1, P) << 1));
                             const unsigned xo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 5) + (p & 31)) << 4) + (o & 4));
-                            qa = *reinterpret_cast<const v2i *>(xb + xo); qb = *reinterpret_cast<const v2i *>(xb + xo + 16);
+                            qa = qb = v2i{0, 0};
+                            if (a.live_slots <= 0 || p < a.live_slots) {
+                                qa = *reinterpret_cast<const v2i *>(xb + xo); qb = *reinterpret_cast<const v2i *>(xb + xo + 16);
+                            }
                         }
                         w[0] = (int32_t)perm((unsigned)qa[0], (unsigned)qb[0], 0x05040100u);
                         w[1] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x05040100u);

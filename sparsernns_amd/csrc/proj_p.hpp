@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                             const int32_t o0 = __builtin_amdgcn_ds_swizzle(q[0], 0x401f), o2 = __builtin_amdgcn_ds_swizzle(q[2], 0x401f);
                             const v2i item = pack4_i16(o0, o2, q[1], q[3]);
                             // pair16_half(b0, (t0 + o) >> 2, p, cc): the tile's first block of state group 0 is the uniform base
-                            if (live) {
+                            if (live && (a.live_slots <= 0 || p < a.live_slots)) {
                                 char *qb = reinterpret_cast<char *>(reinterpret_cast<int16_t *>(a.bq) + pair16_half(b0, t0 >> 2, 0, 0, a.TB, PC));
                                 const unsigned qo = 2u * (unsigned)((((((p >> 5) * (a.TB >> 1) + (o >> 3)) << 6) + 2 * (p & 31) + cc) * 8) + 4 * ((o >> 2) & 1));
                                 *reinterpret_cast<v2i *>(qb + qo) = item;

@@ -314,6 +314,7 @@ struct ModelCfg {
     bool pair_global = false; // S5FXP_PAIR_GLOBAL: pair kernel fed from an int32 K stream in global memory (no helper wave)
     bool no_pk16 = false;     // S5FXP_NO_PK16: unpacked epilogues in the gate kernel
     bool no_compact = false;  // S5FXP_NO_COMPACT: never run a layer on its live states only (s5fxp_fast.hpp FastLayer)
+    bool no_live_lanes = false; // S5FXP_NO_LIVE_LANES: the recurrence streams of a compacted layer keep their padding slots
     bool no_dec_resid = false; // S5FXP_NO_DEC_RESID: the last layer's residual pass as its own launch (proj_p.hpp k_dec_p<.., RESID>)
     int pairl_blocks = 32;    // S5FXP_PAIRL_BLOCKS=16: 16 time blocks per LDS buffer of the LDS-fed pair kernel
     size_t plane_skew = 0;    // S5FXP_PLANE_SKEW=<bytes, multiple of 256>: extra distance between the workspace's planes (experiments)
@@ -328,7 +329,7 @@ struct ModelCfg {
             return (int64_t)(v > 0 ? v : dflt);
         };
         c.debug_sync = on("S5FXP_DEBUG_SYNC"); c.no_bn_ext = on("S5FXP_NO_BN_EXT"); c.no_pair = on("S5FXP_NO_PAIR");
-        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT"); c.no_dec_resid = on("S5FXP_NO_DEC_RESID");
+        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT"); c.no_dec_resid = on("S5FXP_NO_DEC_RESID"); c.no_live_lanes = on("S5FXP_NO_LIVE_LANES");
         { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); c.pairl_blocks = e && std::atoi(e) == 16 ? 16 : 32; }
         { const char *e = std::getenv("S5FXP_PLANE_SKEW"); c.plane_skew = e ? ((size_t)std::atoll(e) & ~(size_t)255) : 0; }
         c.cap_enc = cap("S5FXP_WGS_ENC", c.cap_enc); c.cap_dec = cap("S5FXP_WGS_DEC", c.cap_dec);
@@ -863,6 +864,7 @@ extern "C" int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x
         for (int li = 0; li < m->n_layers; ++li) {
             si.rk[li] = m->layers[li].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
             si.slots[li] = m->P;
+            si.stream[li] = m->P;
         }
         hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
     }
@@ -926,6 +928,7 @@ extern "C" int s5fxp_layer_forward(const s5fxp_model *m, int layer, const int32_
         si.path = S5FXP_PATH_GENERIC;
         si.rk[layer] = m->layers[layer].quad_ok && !(m->flags & S5FXP_MODEL_FORCE_GENERIC) ? 1 : 0;
         si.slots[layer] = m->P;
+        si.stream[layer] = m->P;
         hipLaunchKernelGGL(k_clear2, dim3(1), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, (int32_t *)nullptr, 0, si, m->n_layers, GroupOff{});
     }
     if ((rc = hip_rc(hipMemsetAsync(dyn, 0, sizeof(LayerDyn) * (size_t)m->n_layers, st)))) return rc;

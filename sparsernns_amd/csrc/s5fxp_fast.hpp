@@ -291,6 +291,18 @@ Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced, bool 
     return r;
 }
 
+// State slots a compacted layer keeps in its two recurrence streams, or 0 = all of them: on the LDS-fed pair rung a layer on
+// ONE group of 32 slots stores and loads only its live slots, as whole lane quads = state pairs (scan_quad.hpp
+// ScanPairLArgs::live_lanes; producer k_bproj_p<.., SM = 3>, consumer k_cgate_p<.., PAIR>).
+int stream_live_slots(const s5fxp_model *m, int li, const Rung &rung, bool compact)
+{
+    const FastLayer &fl = m->fast->layers[li];
+    if (!(compact && rung.pairl && fl.c_slots == 32) || m->cfg.no_live_lanes) return 0;
+    int n = 2 * ((fl.n_live + 1) / 2);
+    n = n < 2 ? 2 : n;
+    return n >= 32 ? 0 : n;
+}
+
 // G > 1: a grouped launch (include/s5fxp.h s5fxp_forward_opts::groups): x, y, workspace, status and the carry arrays hold G
 // consecutive copies of what one forward uses; every kernel runs with gridDim.y = G (scan_quad.hpp GroupOff).  The caller
 // (s5fxp_model_forward) sends only hook-free, trace-free forwards here with G > 1.
@@ -357,6 +369,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const bool compact = F.layers[li].compact_ok && !cfg.no_compact && !traces && !state_in && !state_out;
         si.rk[li] = select_rung(m, li, fwd_flags, traces != nullptr, compact).code;
         si.slots[li] = compact ? F.layers[li].c_slots : m->P;
+        const int ls = stream_live_slots(m, li, select_rung(m, li, fwd_flags, traces != nullptr, compact), compact);
+        si.stream[li] = ls ? ls : si.slots[li];
     }
     hipLaunchKernelGGL(k_clear2, dim3(8, G), dim3(256), 0, st, status, (int)S5FXP_STATUS_WORDS, reinterpret_cast<int32_t *>(dyn),
                        (int)(w.dyn_bytes / 4), si, m->n_layers, go);
@@ -491,6 +505,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const bool quad = rung.quad, s16 = rung.s16, pair = rung.pair, pairl = rung.pairl;
         const int32_t l_pair_xmax = compact ? fl.c_bounds.pair_xmax : l.pair_xmax, l_quad_xmax = compact ? fl.c_bounds.quad_xmax : l.quad_xmax;
         const int P = compact ? fl.c_slots : m->P;
+        // on the LDS-fed pair rung a compacted layer with ONE group of 32 slots keeps only its live slots in the two recurrence
+        // streams (whole lane quads = state pairs; scan_quad.hpp ScanPairLArgs::live_lanes): 0 = every slot
+        const int live_slots = stream_live_slots(m, li, rung, compact);
         const int32_t *la_re = compact ? fl.c_a_re : l.a_re, *la_im = compact ? fl.c_a_im : l.a_im;
         const MfmaW &w_bproj = compact ? fl.c_bproj.w : fl.bproj.w, &w_bproj_pair = compact ? fl.c_bproj_pair.w : fl.bproj_pair.w;
         const MfmaW &w_cre = compact ? fl.c_cre.w : fl.cre.w, &w_cim = compact ? fl.c_cim.w : fl.cim.w;
@@ -503,6 +520,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.rs_re = s.u_exp + s.B_re_exp - s.Bu_re_exp; a.rs_im = s.u_exp + s.B_im_exp - s.Bu_im_exp;
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
             a.k_re = 65536 - (1 << (16 - s.A_re_exp));
+            a.live_slots = live_slots;
             if (fold) {
                 a.ext = reinterpret_cast<const float *>(ws + w.ext) + (size_t)li * 2 * H * EXT_REPS;
                 a.ext_reps = EXT_REPS; a.status = status; a.status_exps = st_exps;
@@ -563,7 +581,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (pairl) {
             ScanPairLArgs q{};
             q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im; q.live_lanes = 2 * live_slots;
             // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
             // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
             const int blocks = cfg.pairl_blocks;
@@ -632,6 +650,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             std::memcpy(a.lut, l.lut, sizeof(a.lut));
             a.l_bits = l.l_bits; a.l_exp = l.l_exp; a.r_bits = l.r_bits; a.r_exp = l.r_exp; a.res_bits = l.res_bits;
             a.res_exp = l.res_exp; a.rs_gate = ga.rs_gate; a.skip_e = he; a.dynw = d; a.status = status;
+            a.live_slots = live_slots;
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);

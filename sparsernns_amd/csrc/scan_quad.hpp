@@ -462,6 +462,11 @@ struct ScanPairLArgs {
     int32_t B, TB, P;           // TB % BLOCKS == 0 (k_scan_pairl_asm<BLOCKS>)
     int32_t ea_re, ea_im;
     const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
+    // lanes 2p, 2p+1 belong to state slot p of the wave's 32.  live_lanes > 0 (a compacted layer, s5fxp_fast.hpp): only the
+    // first live_lanes lanes -- the live states, rounded up to whole lane quads -- exist; the others leave at once in BOTH
+    // waves, so the padding slots' share of the two streams is neither read nor written (their producer and consumer skip
+    // the same slots: k_bproj_p<.., SM = 3> and k_cgate_p<.., PAIR>)
+    int32_t live_lanes;
 };
 
 template <int... J, class F>
@@ -481,6 +486,7 @@ __global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a, GroupOf
     extern __shared__ __attribute__((aligned(16))) int32_t kbuf[]; // three buffers of BLOCKS KB
     constexpr int BUFW = BLOCKS * 256;                              // words per buffer
     const int lane = threadIdx.x & 63;
+    if (a.live_lanes > 0 && lane >= a.live_lanes) return; // padding slots of a compacted layer (ScanPairLArgs)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: recurrence, 1: helper
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);         // (b, state group of 32)
     const int n_it = a.TB / BLOCKS;

@@ -22,9 +22,14 @@ def read(path, ctr):
     return vals
 
 
+try:  # the bench line of the same profiling run says how many state slots the recurrence streams of each layer held
+    line = [l for l in open(f"{prefix}_g8_single.json") if l.startswith("{")][-1]
+    stream_slots = json.loads(line)["roofline"]["stream_slots_per_layer"]
+except (OSError, KeyError, IndexError):
+    stream_slots = [32, 32, 32]
 doc = dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over bench.py --inflight 1 (tools/prof_r03.sh); "
-                "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1000); B=32, L=4096, dim_scale 0.5, layers compacted to 32 live-state slots",
-           B=32, L=4096, P=64, state_slots=[32, 32, 32], entries=[])
+                "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1000); B=32, L=4096, dim_scale 0.5, layers compacted to 32 state slots, recurrence streams on the live ones (stream_slots)",
+           B=32, L=4096, P=64, stream_slots=stream_slots, entries=[])
 for g in (1, 8):
     f, w = read(f"{prefix}_pmc_fetch_g{g}.txt", "FETCH_SIZE"), read(f"{prefix}_pmc_write_g{g}.txt", "WRITE_SIZE")
     per = {k: int(round((2 * f[k] + w[k]) * 1000)) for k in KERNELS if k in f and k in w}
