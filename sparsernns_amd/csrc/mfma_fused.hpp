@@ -33,7 +33,7 @@ struct CGateArgs {
     LayerDyn *dynw;
     int32_t *status;
     int32_t bad_bits; // status bits raised when a state is out of range (k_cgate_p)
-    int32_t live_slots; // PAIR, > 0: state slots at or above it are zero and not in the stream (scan_quad.hpp ScanPairLArgs)
+    int32_t live_slots; // S16, > 0: state slots at or above it are zero and not in the stream (scan_quad.hpp ScanPairLArgs)
     int32_t t_lo, t_len; // k_cgate_p: the step range this launch covers (StepRange)
     const int32_t *sigtab; // [2][7 << sig_x]: gate operand r for a non-positive / positive sigmoid input (k_cgate_p)
     const int32_t *run_if; // WIDE (exact re-run): do the work only when *run_if != 0 (nullptr: always)
@@ -391,7 +391,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                         w[3] = (int32_t)perm((unsigned)qb[1], (unsigned)qa[1], 0x07060302u);
                     } else {
                     // 16 bytes: re of steps 0..3, then im of steps 0..3, as int16; w[j] = re_j | im_j << 16 by two perms
-                    const v4i q4 = *reinterpret_cast<const v4i *>(reinterpret_cast<const int16_t *>(a.xs) + native_word(b0, t0 + o, p, 0, a.TB, P));
+                    v4i q4 = {0, 0, 0, 0};
+                    if (a.live_slots <= 0 || p < a.live_slots)
+                        q4 = *reinterpret_cast<const v4i *>(reinterpret_cast<const int16_t *>(a.xs) + native_word(b0, t0 + o, p, 0, a.TB, P));
                     w[0] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x05040100u);
                     w[1] = (int32_t)perm((unsigned)q4[2], (unsigned)q4[0], 0x07060302u);
                     w[2] = (int32_t)perm((unsigned)q4[3], (unsigned)q4[1], 0x05040100u);

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                             item[3] = wadd(wshl(q[3], 16), kc);
                             if (live) *reinterpret_cast<v4i *>(a.bq + pair_word(b0, (t0 + o) >> 2, p, a.TB, PC) + 4 * cc) = item;
                         } else if (SM == 1) {
-                            if (live)
+                            if (live && (a.live_slots <= 0 || p < a.live_slots))
                                 *reinterpret_cast<v2i *>(reinterpret_cast<int16_t *>(a.bq) + native_word(b0, t0 + o, p, cc, a.TB, PC)) =
                                     pack4_i16(q[0], q[1], q[2], q[3]);
                         } else if (live)

@@ -291,16 +291,17 @@ Rung select_rung(const s5fxp_model *m, int li, int fwd_flags, bool traced, bool 
     return r;
 }
 
-// State slots a compacted layer keeps in its two recurrence streams, or 0 = all of them: on the LDS-fed pair rung a layer on
-// ONE group of 32 slots stores and loads only its live slots, as whole lane quads = state pairs (scan_quad.hpp
-// ScanPairLArgs::live_lanes; producer k_bproj_p<.., SM = 3>, consumer k_cgate_p<.., PAIR>).
+// State slots a compacted layer keeps in its two recurrence streams, or 0 = all of them: on the two int16 rungs (LDS-fed pair
+// kernel, quad16) the padding slots are neither stored nor loaded -- whole state pairs, so that the pair kernel keeps whole
+// lane quads (scan_quad.hpp ScanPairLArgs::live_slots; producers k_bproj_p<.., SM = 3 / 1>, consumer k_cgate_p<.., S16>).
 int stream_live_slots(const s5fxp_model *m, int li, const Rung &rung, bool compact)
 {
     const FastLayer &fl = m->fast->layers[li];
-    if (!(compact && rung.pairl && fl.c_slots == 32) || m->cfg.no_live_lanes) return 0;
+    const bool int16_rung = rung.pairl || (rung.quad && rung.s16 && !rung.pair);
+    if (!(compact && int16_rung) || rung.exact || m->cfg.no_live_lanes) return 0;
     int n = 2 * ((fl.n_live + 1) / 2);
     n = n < 2 ? 2 : n;
-    return n >= 32 ? 0 : n;
+    return n >= fl.c_slots ? 0 : n;
 }
 
 // G > 1: a grouped launch (include/s5fxp.h s5fxp_forward_opts::groups): x, y, workspace, status and the carry arrays hold G
@@ -581,7 +582,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         if (pairl) {
             ScanPairLArgs q{};
             q.b16 = I16(w.bq); q.xs = I16(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im; q.live_lanes = 2 * live_slots;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im; q.live_slots = live_slots;
             // one helper wave (a second one lands on the computing wave's side of the LDS path and costs more than it
             // helps: profiles/r02_ubench_pair.log).  Blocks per LDS buffer = steps per s_barrier / 4: S5FXP_PAIRL_BLOCKS
             const int blocks = cfg.pairl_blocks;
@@ -604,7 +605,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         } else if (quad) {
             ScanQuadArgs q{};
             q.bq = I32(w.bq); q.xs = I32(w.xs); q.a_re = la_re; q.a_im = la_im; q.B = B; q.TB = w.TB; q.P = P;
-            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im;
+            q.ea_re = s.A_re_exp; q.ea_im = s.A_im_exp; q.x0_re = x0_re; q.x0_im = x0_im; q.live_slots = live_slots;
             {
                 if (s16) launch_scan(k_scan_quad_asm16, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);
                 else launch_scan(k_scan_quad_asm, dim3((unsigned)((int64_t)B * P / 16)), dim3(64), q);

@@ -126,6 +126,7 @@ struct ScanQuadArgs {
     int32_t tb0, ntb;           // k_scan_quad_asm: first time block and block count of this launch (0, 0 = all)
     const int32_t *run_if;      // k_scan_quad32_asm: do the work only when *run_if != 0 (nullptr: always)
     const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
+    int32_t live_slots;         // k_scan_quad_asm16, > 0: state slots at or above it are not in the streams (ScanPairLArgs)
 };
 
 // the state a quad lane holds before an even step: lanes 0,3 the real part, lanes 1,2 the imaginary part
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(64) void k_scan_quad_asm16(ScanQuadArgs a, GroupOff
     u32x4 rin, rout;
     rin[0] = (unsigned)bin; rin[1] = (unsigned)(bin >> 32) & 0xffffu; rin[2] = extent; rin[3] = 0x00020000u;
     rout[0] = (unsigned)bout; rout[1] = (unsigned)(bout >> 32) & 0xffffu; rout[2] = extent; rout[3] = 0x00020000u;
-    const unsigned voff = r < 2 ? (unsigned)(s * 16 + r * 8) : 0xFFFFFF00u;
+    // out-of-range buffer offsets: loads return 0, stores are dropped -- the lanes that do not touch memory, and every lane of a
+    // padding slot of a compacted layer (its Bu is 0 and so is its state)
+    const unsigned voff = r < 2 && (a.live_slots <= 0 || p < a.live_slots) ? (unsigned)(s * 16 + r * 8) : 0xFFFFFF00u;
     unsigned sld = 0, sst = 0, cnt = (unsigned)a.TB / S5_SCAN_ASM_DEPTH;
     asm volatile(S5_SCAN16_ASM_BODY
                  : [sld] "+s"(sld), [sst] "+s"(sst), [cnt] "+s"(cnt)
@@ -462,11 +465,11 @@ struct ScanPairLArgs {
     int32_t B, TB, P;           // TB % BLOCKS == 0 (k_scan_pairl_asm<BLOCKS>)
     int32_t ea_re, ea_im;
     const int32_t *x0_re, *x0_im; // (B,P) state before the first step (streaming carry), nullptr = zeros
-    // lanes 2p, 2p+1 belong to state slot p of the wave's 32.  live_lanes > 0 (a compacted layer, s5fxp_fast.hpp): only the
-    // first live_lanes lanes -- the live states, rounded up to whole lane quads -- exist; the others leave at once in BOTH
-    // waves, so the padding slots' share of the two streams is neither read nor written (their producer and consumer skip
-    // the same slots: k_bproj_p<.., SM = 3> and k_cgate_p<.., PAIR>)
-    int32_t live_lanes;
+    // lanes 2p, 2p+1 belong to state slot p of the wave's 32.  live_slots > 0 (a compacted layer, s5fxp_fast.hpp: the live
+    // states, rounded up to an even number so that whole lane quads remain): the lanes of the slots at or above it leave at
+    // once in BOTH waves, so the padding slots' share of the two streams is neither read nor written (their producer and
+    // consumer skip the same slots: k_bproj_p<.., SM = 3> and k_cgate_p<.., PAIR>)
+    int32_t live_slots;
 };
 
 template <int... J, class F>
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(128) void k_scan_pairl_asm(ScanPairLArgs a, GroupOf
     extern __shared__ __attribute__((aligned(16))) int32_t kbuf[]; // three buffers of BLOCKS KB
     constexpr int BUFW = BLOCKS * 256;                              // words per buffer
     const int lane = threadIdx.x & 63;
-    if (a.live_lanes > 0 && lane >= a.live_lanes) return; // padding slots of a compacted layer (ScanPairLArgs)
+    if (a.live_slots > 0 && (((int)blockIdx.x % (a.P >> 5)) << 5) + (lane >> 1) >= a.live_slots) return; // padding slots of a compacted layer
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // 0: recurrence, 1: helper
     const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x);         // (b, state group of 32)
     const int n_it = a.TB / BLOCKS;

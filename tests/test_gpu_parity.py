@@ -1057,6 +1057,10 @@ def test_layers_run_on_their_live_states_only(ds, monkeypatch):
         eng.enqueue(x, fx.bits, fx.exp, y, B, L, flags=flags)
         redo = bool(int(eng.check_status()[0]) & _lib.ST_REDO)
         assert slots(eng) == want, (flags, slots(eng), live)
+        # the two int16 rungs keep only the live slots (whole state pairs) in their recurrence streams: status word [8 + 8l + 7]
+        stream = [int(v) for v in eng.lane_status(0).cpu().numpy()[8 + 7:8 + 8 * nl:8]]
+        int16_rung = bool(flags & _lib.FWD_DEFER_REDO)
+        assert stream == [min(w, max(2, 2 * ((n + 1) // 2))) if int16_rung else w for n, w in zip(live, want)], (flags, stream)
         if flags == _lib.FWD_DEFER_REDO:   # the top rung asks for a repeat exactly when a live state passes its bound
             assert redo == any(t > b for t, b in zip(tops, bounds)), (tops, bounds)
         else:
