@@ -435,6 +435,7 @@ struct BprojM2Args {
     int32_t rs_re, rs_im, bre_bits, bim_bits, sh_re, sh_im;
     int32_t t_lo, t_len; // k_bproj_p: the step range this launch covers (StepRange)
     int32_t k_re;        // SM = 2 (pair-native K stream): 2^16 - 2^(16 - A_re_exp), the addend of the negated product
+    int32_t no_u;        // != 0: u is not stored -- the gate kernel recomputes it (mfma_fused.hpp k_cgate_p<.., GBN>)
     int32_t live_slots;  // SM = 3 / 1, > 0: only state slots below it are stored (scan_quad.hpp ScanPairLArgs::live_slots)
     // != nullptr: the per-channel extremes of the layer input (ext_reps replicas of 2H floats); every workgroup derives the
     // BatchNorm exponents from them in its prologue (bn_finalize_mm_body), workgroup 0 publishes them

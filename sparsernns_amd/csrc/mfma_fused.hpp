@@ -13,6 +13,7 @@ using v2i16 = __attribute__((ext_vector_type(2))) short;
 
 struct CGateArgs {
     const int16_t *u;    // (N,H) SSM input (written by the B projection)
+    BnArgs bn;           // GBN instantiations: this layer's BatchNorm; u is recomputed from `skip` and `u` is not read
     const int16_t *skip; // (N,H) layer input
     const int32_t *xs;   // native raw states
     MfmaW w_re, w_im;    // H channels each, K = P
@@ -182,7 +183,11 @@ constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
 // PK16 (with DIRECT): y, out2 output, the gate's l operand and its result are all 16 bit, no out2 input conversion and
 // every |bias_eff| fits 16 bits (host-checked, s5fxp_fast.hpp): both epilogues run on packed int16 pairs -- saturating
 // packs, clamped packed sub / mad / add, SDWA half-word operands -- about a third fewer VALU instructions, same results
-template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false, bool PK16 = false>
+// GBN (with PK16): the SSM input u = BatchNorm(layer input) is recomputed here from `skip` -- the layer input this kernel reads
+// anyway for the residual maxima -- with the exponents the B projection left in LayerDyn, instead of being written by the B
+// projection and read back: -2 x N x H x 2 bytes of traffic per layer for ~12 more VALU operations per element (mfma_bn.hpp bn16_x4)
+template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int FTP = 64, bool WIDE = false, bool PAIR = false, bool PK16 = false,
+          bool GBN = false>
 // <= 128 registers: two six-wave workgroups per CU (at 136 only one was ever resident: measured)
 // -DS5_CGATE_HID=1: states, u and skip of the NEXT tile all requested a tile ahead behind the compiler's back and waited for
 // by exact count (scan_quad.hpp vm_wait).  Measured (profiles/r03_gate_prefetch_ab.txt): 226 us per 8-batch launch against
@@ -202,7 +207,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
         const int64_t g = blockIdx.y;
         gshift(a.u, g * go.ws); gshift(a.skip, g * go.ws); gshift(a.xs, g * go.ws); gshift(a.z, g * go.ws);
         gshift(a.skip_e.dyn, g * go.ws); gshift(a.dynw, g * go.ws); gshift(a.run_if, g * go.ws); gshift(a.status, g * go.status);
+        if constexpr (GBN) { gshift(a.bn.dyn, g * go.ws); gshift(a.bn.xe.dyn, g * go.ws); }
     }
+    static_assert(!GBN || (PK16 && !TRACE && !WIDE), "the BatchNorm rides on the packed-epilogue kernel only");
     constexpr int P = 32 * KS, H = 32 * NT, FT = FTP, NW = (FT / 32) * NT, NTHR = 64 * NW; // one wave per (half, column tile)
     constexpr int KPS = 2 * P + 16, KPX = H + 16;
     constexpr int NU = 1, SUBSTEP = 0;   // units per wave
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     int8_t *Sbase = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? SIGDIR_BYTES : 4 * SIGTAB_WORDS);
     int8_t *Sl = Sbase, *Sh = Sbase + (NPL - 1) * FT * KPS, *Xh = Sbase + NPL * FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
+    int32_t *bntab = reinterpret_cast<int32_t *>(red + 48); // GBN: 4 * H BatchNorm operands (bn16_setup)
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
     const StepRange sr{a.t_lo, a.t_len};
@@ -249,6 +257,8 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     } else {
         for (int i = threadIdx.x; i < (14 << a.sig_x); i += NTHR) sigt[i] = a.sigtab[i];
     }
+    Bn16 bn{};
+    if constexpr (GBN) bn = bn16_setup(a.bn, *a.bn.dyn, bntab, H); // the B projection of this layer has published the exponents
     const int dsh = a.out_exp - a.sig_x, dbias = 1 << (a.sigdir_bits - 1);
     const int skip_e = a.skip_e.get();
     const float kz = ldexpf(1.f, skip_e - a.res_exp); // fz + fs = 2^-skip_e * (z * kz + s), exactly
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     };
     if ((int64_t)blockIdx.x < tiles) {
         if constexpr (XPRE) load_x(blockIdx.x);
-        load_rows(uq, a.u, blockIdx.x);
+        if constexpr (!GBN) load_rows(uq, a.u, blockIdx.x);
         load_rows(sq, a.skip, blockIdx.x);
     }
     __syncthreads();
@@ -459,12 +469,23 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                 const int off = (32 * sub + r) * KPX + ch0 + 8 * g;
                 if constexpr (PK16) {
                     // fxpmodel.py:746-793 + :1125 on int16 pairs: cx = sat(sat(cr) - sat(ci)); y = sat(2 cx + sat(D u)); x1 = max(y, 0)
+                    int32_t ubn[4];
+                    if constexpr (GBN) { // u = BatchNorm(layer input) of these four channels, as the B projection computes it
+                        int32_t hin[4], tbn[4];
+                        unpack4_i16(sq[u][g], hin);
+                        bn16_x4(bn, hin, ch0 + 8 * g, tbn, ubn);
+                    }
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const uint32_t crp = pk_cvt(asr(are[4 * g + 2 * q], a.rs_re), asr(are[4 * g + 2 * q + 1], a.rs_re));
                         const uint32_t cip = pk_cvt(asr(aim[4 * g + 2 * q], a.rs_im), asr(aim[4 * g + 2 * q + 1], a.rs_im));
-                        const uint32_t upk = (uint32_t)uq[u][g][q];
-                        const uint32_t dup = pk_cvt(asr(mul24_h<0>(Dv[2 * q], upk), a.rs_d), asr(mul24_h<1>(Dv[2 * q + 1], upk), a.rs_d));
+                        uint32_t dup;
+                        if constexpr (GBN) {
+                            dup = pk_cvt(asr(__mul24(Dv[2 * q], ubn[2 * q]), a.rs_d), asr(__mul24(Dv[2 * q + 1], ubn[2 * q + 1]), a.rs_d));
+                        } else {
+                            const uint32_t upk = (uint32_t)uq[u][g][q];
+                            dup = pk_cvt(asr(mul24_h<0>(Dv[2 * q], upk), a.rs_d), asr(mul24_h<1>(Dv[2 * q + 1], upk), a.rs_d));
+                        }
                         const uint32_t yp = pk_mad_sat(pk_sub_sat(crp, cip), 0x00020002u, dup); // 2*cx is not clipped, :765-767
                         x1p[u][2 * g + q] = pk_max(yp, 0u);
                     }
@@ -498,7 +519,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                 }
             }
         }
-        if (tile_next < tiles) load_rows(uq, a.u, tile_next); // the first epilogue is done with u
+        if constexpr (!GBN) {
+            if (tile_next < tiles) load_rows(uq, a.u, tile_next); // the first epilogue is done with u
+        }
         lds_barrier();
         if constexpr (HID) { // newer: x(next) and u(next), if there is a next tile
             if (tile_next < tiles) vm_wait<NX_MIN + 4>(sq);

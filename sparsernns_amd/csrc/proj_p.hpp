@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                     reinterpret_cast<int32_t(&)[4]>(u[0]));
             bn16_x4(bn, reinterpret_cast<const int32_t(&)[4]>(xin[4]), 8 * og + 4, reinterpret_cast<int32_t(&)[4]>(t[4]),
                     reinterpret_cast<int32_t(&)[4]>(u[4]));
-            if (f < nvalid) {
+            if (f < nvalid && (TRACE || !a.no_u)) {
                 const v2i p0 = pack4_i16(u[0], u[1], u[2], u[3]), p1 = pack4_i16(u[4], u[5], u[6], u[7]);
                 *reinterpret_cast<v4i *>(ub + 2u * (unsigned)(f * H + 8 * og)) = v4i{p0[0], p0[1], p1[0], p1[1]};
                 if (TRACE) {

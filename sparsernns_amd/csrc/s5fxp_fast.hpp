@@ -512,6 +512,16 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         const int32_t *la_re = compact ? fl.c_a_re : l.a_re, *la_im = compact ? fl.c_a_im : l.a_im;
         const MfmaW &w_bproj = compact ? fl.c_bproj.w : fl.bproj.w, &w_bproj_pair = compact ? fl.c_bproj_pair.w : fl.bproj_pair.w;
         const MfmaW &w_cre = compact ? fl.c_cre.w : fl.cre.w, &w_cim = compact ? fl.c_cim.w : fl.cim.w;
+        // packed int16 epilogues of the gate kernel (mfma_fused.hpp PK16): every width they touch is 16, no out2 input conversion
+        const bool out2_conv = s.y_bits > l.out2.inp_bits || s.y_exp > l.out2.inp_exp;
+        const bool direct = s16 && fl.sigdir_bits > 0;
+        const bool pk16 = direct && !tr && !cfg.no_pk16 && fl.bias16 && s.y_bits == 16 && l.out2.out_bits == 16 && l.res_bits == 16 &&
+                          l.l_bits == 16 && !out2_conv && l.l_exp - s.y_exp <= 14;
+        // ... and on that kernel the SSM input u CAN be recomputed from the layer input instead of travelling through memory
+        // (k_cgate_p<.., GBN>, S5FXP_GATE_BN=1; the exponents are the ones this layer's B projection publishes in its prologue).
+        // Off by default: -50 MB per layer and batch, but the twelve VALU operations per element land in the kernel that is
+        // VALU-co-limited already -- gate kernel 207 -> 250 us per 8-batch launch, B projection 104 -> 90: 3 % slower overall
+        const bool gate_bn = pk16 && fold && !big && cfg.gate_bn;
         {
             BprojM2Args a{};
             a.bn = bn; a.x = h; a.w = w_bproj; a.bq = I32(w.bq); a.u = I16(w.u);
@@ -522,6 +532,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.bre_bits = s.Bu_re_bits; a.bim_bits = s.Bu_im_bits; a.sh_re = sh_re; a.sh_im = sh_im;
             a.k_re = 65536 - (1 << (16 - s.A_re_exp));
             a.live_slots = live_slots;
+            a.no_u = gate_bn ? 1 : 0;
             if (fold) {
                 a.ext = reinterpret_cast<const float *>(ws + w.ext) + (size_t)li * 2 * H * EXT_REPS;
                 a.ext_reps = EXT_REPS; a.status = status; a.status_exps = st_exps;
@@ -655,12 +666,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             // phase-split fused kernel (mfma_fused.hpp): six waves per workgroup, 64-frame tiles, no weights in LDS
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
-            const bool direct = s16 && fl.sigdir_bits > 0;
-            // packed int16 epilogues (mfma_fused.hpp PK16): every width they touch is 16, no out2 input conversion
-            const bool pk16 = direct && !tr && !cfg.no_pk16 && fl.bias16 && s.y_bits == 16 && ga.out_bits == 16 && l.res_bits == 16 &&
-                              l.l_bits == 16 && !ga.conv && l.l_exp - s.y_exp <= 14;
+            a.bn = bn;
             const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
-                                2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192;
+                                2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192 + (gate_bn ? 16 * (size_t)H : 0);
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 for (int g = 0; g < G; ++g)
@@ -678,6 +686,9 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                             if (compact && P == 32) launch6g(k_cgate_p<1, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                             else if (compact) launch6g(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                             else launch6g(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                        } else if (PK_ && gate_bn) {
+                            if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
+                            else launch6g(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
                         } else {
                             if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
                             else launch6g(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
