@@ -246,7 +246,7 @@ def main() -> None:
 
     exact_mode = False
 
-    def run(steps, d, events=None, g=None):
+    def run(steps, d, events=None, g=None, gate_events=None):
         """`steps` forwards (= batches) as launch sets of g batches each (the last set takes what is left), d sets in flight.
         d > 1: optimistic mode (the gated exact re-run launches are dropped); the status words of every lane are checked
         afterwards and must not carry ST_REDO."""
@@ -257,7 +257,7 @@ def main() -> None:
             for k in range(sets):
                 gk = min(g, steps - k * g)
                 eng.enqueue(fx.data, fx.bits, fx.exp, y, B, L, None, allreduce, flags=flags,
-                            scan_events=events[k] if events else None, groups=gk)
+                            scan_events=events[k] if events else None, groups=gk, gate_events=gate_events[k] if gate_events else None)
             return None
         runner = InflightRunner(eng, d) if run.runner is None else run.runner
         run.runner = runner
@@ -321,13 +321,14 @@ def main() -> None:
     st0 = check_all(depth)
 
     # ---- the same K steps one launch set at a time (no overlap between sets), for reference; not the headline
-    single, ev1 = None, None
+    single, ev1, evg = None, None, None
     if depth > 1 or G > 1:
         ev1 = make_events(n_sets(args.steps, G))
+        evg = make_events(n_sets(args.steps, G))  # ... and one layer's gate-kernel launch another pair
         run(G, 1)  # lane 0's workspace for G groups exists before the clock starts
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run(args.steps, 1, ev1)
+        run(args.steps, 1, ev1, gate_events=evg)
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
         check_all(1)
@@ -419,6 +420,23 @@ def main() -> None:
                                            "set at a time", moved_bytes_source="PMC (profiles/r03_scan_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)" if tg is not None else "stream sizes",
                         one_batch_launch=one)
 
+    # ---- the slowest kernel of the forward, measured the same way (events attached to its launches of the one-set-at-a-time pass):
+    # the gate kernel (C projection + out2 + sigmoid gate).  SURVEY.md 8(d) defines no algorithmic byte count for it, so its
+    # rate is on the bytes it moves (PMC passes of the same workload, when committed).
+    gate_kernel = None
+    if evg is not None and optimistic and not allreduce:
+        try:
+            gate_s = scan_avg(evg)
+        except RuntimeError:  # the events were not attached (a path that does not run the fused gate kernel)
+            gate_s = None
+        if gate_s:
+            tgk = pmc_traffic(B, L, dims["P"], "k_cgate_p", G, stream_slots)
+            gate_kernel = dict(kernel="k_cgate_p (C projection + D u, out2, table sigmoid, gate, residual maxima)", avg_kernel_us=round(gate_s * 1e6, 2),
+                               batches_per_launch=G, traffic=tgk,
+                               achieved=round(tgk / gate_s / 1e9, 1) if tgk else None, unit="GB/s", peak=HBM_PEAK_GBS,
+                               frac_moved=round(tgk / gate_s / 1e9 / HBM_PEAK_GBS, 4) if tgk else None,
+                               note="VALU co-limited (DESIGN.md 4a): 51 M VALU instructions per 8-batch launch beside 0.68 GB of traffic")
+
     # ---- the recurrence kernel with more chains than one reference batch gives it (not the headline workload): at
     # B=32 its launch is a latency chain on 128 waves, whatever the bandwidth; the same kernel at 4x the batch shows
     # what it moves when the chip is filled.  Single stream, a few steps, rank 0 of a 1-GPU run only.
@@ -504,7 +522,7 @@ def main() -> None:
                         stream_width="int32 arithmetic and model input / output; int16 activations between kernels and int16 "
                                      "range-guarded recurrence streams (a value outside the guarded range repeats the batch on "
                                      "the exact int32 kernels)"),
-            roofline=roofline, recurrence_kernel_at_4x_batch=scan_big, cpu_baseline=cpu, single_stream=single,
+            roofline=roofline, gate_kernel=gate_kernel, recurrence_kernel_at_4x_batch=scan_big, cpu_baseline=cpu, single_stream=single,
             mode="ABLATED BUILD, STATUS IGNORED: not a result" if ablated else (fallback_note or ("optimistic" if optimistic else "self-contained")),
             status_bits=int(st0),
             output_gather_ms=gather_ms, rank_values=rank_values)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S5FXP_VERSION 101
+#define S5FXP_VERSION 102
 
 enum {
     S5FXP_OK = 0,
@@ -268,6 +268,9 @@ typedef struct {
      * reference's run_validation loop over batches (sparseRNNs/fxprun.py:53-88) taken several batches at a time: at the
      * N-DNS batch of 32 sequences a launch costs about as much as a quarter of its work. */
     int32_t groups;
+    /* Measurement only, like scan_events: 2*n_layers hipEvent_t handles (or NULL) attached to layer l's GATE-kernel launch
+     * (C projection + out2 + gate) on the fused path; ignored elsewhere. */
+    void **gate_events;
 } s5fxp_forward_opts;
 
 /* x: (B,L,d_in) int32 device; y: (B,L,d_out) int32 device; status: S5FXP_STATUS_WORDS int32 device.

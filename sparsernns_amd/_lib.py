@@ -74,7 +74,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, VOIDP, VOIDP, C.c_int, VOIDP)
 
 class ForwardOpts(C.Structure):
     _fields_ = [("allreduce", ALLREDUCE_FN), ("allreduce_ctx", VOIDP), ("scan_events", C.POINTER(VOIDP)),
-                ("flags", C.c_int32), ("state_in", VOIDP), ("state_out", VOIDP), ("groups", C.c_int32)]
+                ("flags", C.c_int32), ("state_in", VOIDP), ("state_out", VOIDP), ("groups", C.c_int32),
+                ("gate_events", C.POINTER(VOIDP))]
 
 
 class S5FxpError(RuntimeError):

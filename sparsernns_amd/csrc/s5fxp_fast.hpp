@@ -333,6 +333,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
     s5fxp_allreduce_max_fn allreduce = opts ? opts->allreduce : nullptr;
     void *allreduce_ctx = opts ? opts->allreduce_ctx : nullptr;
     void **scan_events = opts ? opts->scan_events : nullptr;
+    void **gate_events = opts ? opts->gate_events : nullptr;
     const int32_t *state_in = opts ? opts->state_in : nullptr;
     int32_t *state_out = opts ? opts->state_out : nullptr;
     const bool exact = (fwd_flags & S5FXP_FWD_EXACT) != 0;
@@ -398,6 +399,14 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
         hipLaunchKernelGGL(kernel, dim3(g6, G), dim3(threads), smem, st, args, go);
     };
     auto launch6 = [&](auto kernel, size_t smem, const auto &args) { launch6g(kernel, grid_dec, smem, args); };
+    // the gate kernel's launch can carry a pair of HIP events (s5fxp_forward_opts::gate_events: measurement only)
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;
+    auto launch_gate = [&](auto kernel, unsigned g6, size_t smem, const auto &args, unsigned threads = 384) {
+        if (smem > 65536)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (gev0 && gev1) hipExtLaunchKernelGGL(kernel, dim3(g6, G), dim3(threads), smem, st, gev0, gev1, 0, args, go);
+        else hipLaunchKernelGGL(kernel, dim3(g6, G), dim3(threads), smem, st, args, go);
+    };
     auto launch6x = [&](auto kernel, size_t smem, const auto &args, float *ext, int ext_reps) {
         if (smem > 65536)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -679,19 +688,20 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                     const int64_t tl = (int64_t)B * ((a.t_len + 63) / 64), per = (tl + cap_cgate - 1) / cap_cgate;
                     const unsigned cg = (unsigned)((tl + per - 1) / per);
                     // <S16, DIRECT, PAIR, PK16> of mfma_fused.hpp; KS = state slots / 32 (halved for a compacted layer)
+                    gev0 = gate_events ? (hipEvent_t)gate_events[2 * li] : nullptr; gev1 = gate_events ? (hipEvent_t)gate_events[2 * li + 1] : nullptr;
                     auto cgate = [&](auto s16_t, auto direct_t, auto pair_t, auto pk16_t) {
                         constexpr bool S16_ = decltype(s16_t)::value, DIR_ = decltype(direct_t)::value, PAIR_ = decltype(pair_t)::value,
                                        PK_ = decltype(pk16_t)::value;
                         if (big) {
-                            if (compact && P == 32) launch6g(k_cgate_p<1, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
-                            else if (compact) launch6g(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
-                            else launch6g(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            if (compact && P == 32) launch_gate(k_cgate_p<1, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            else if (compact) launch_gate(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
+                            else launch_gate(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                         } else if (PK_ && gate_bn) {
-                            if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
-                            else launch6g(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
+                            if (compact) launch_gate(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
+                            else launch_gate(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
                         } else {
-                            if (compact) launch6g(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
-                            else launch6g(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
+                            if (compact) launch_gate(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
+                            else launch_gate(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a);
                         }
                     };
                     using T_ = std::true_type;

@@ -172,7 +172,8 @@ class Engine:
     def enqueue(self, x: torch.Tensor, x_bits: int, x_exp: int, y: torch.Tensor, B: int, L: int,
                 traces: Optional[List[Dict[str, torch.Tensor]]] = None, allreduce: Optional[Callable] = None,
                 scan_events: Optional[list] = None, flags: int = 0, lane: int = 0,
-                state_in: Optional[torch.Tensor] = None, state_out: Optional[torch.Tensor] = None, groups: int = 1) -> None:
+                state_in: Optional[torch.Tensor] = None, state_out: Optional[torch.Tensor] = None, groups: int = 1,
+                gate_events: Optional[list] = None) -> None:
         """Launches one forward on the current stream; nothing is synchronised.
 
         groups = G > 1: x and y hold G * B sequences, G independent reference batches of B sequences each (what G calls
@@ -212,6 +213,11 @@ class Engine:
             arr = (C.c_void_p * len(scan_events))(*[(e.cuda_event if e is not None else None) for e in scan_events])
             opts.scan_events = C.cast(arr, C.POINTER(C.c_void_p))
             self._ev_keep = arr
+        if gate_events is not None:
+            assert len(gate_events) == 2 * self.n_layers
+            arr2 = (C.c_void_p * len(gate_events))(*[(e.cuda_event if e is not None else None) for e in gate_events])
+            opts.gate_events = C.cast(arr2, C.POINTER(C.c_void_p))
+            self._ev_keep2 = arr2
         opts.flags = int(flags)
         opts.groups = int(groups)
         want = (self.n_layers, 2, B, self.P) if groups == 1 else (groups, self.n_layers, 2, B, self.P)
