@@ -137,6 +137,19 @@ __device__ __forceinline__ uint32_t pk_ashr(uint32_t a, uint32_t s) // s = shift
     asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "v"(s), "v"(a));
     return r;
 }
+// the same with a wave-uniform second operand taken from an SGPR (no v_mov per use)
+__device__ __forceinline__ uint32_t pk_mul_sat_u(uint32_t a, uint32_t m_uniform) // sat16(a * m) per half
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(r) : "v"(a), "s"(m_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_ashr_u(uint32_t a, uint32_t s_uniform)
+{
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "s"(s_uniform), "v"(a));
+    return r;
+}
 template <int HALF>
 __device__ __forceinline__ int32_t mul24_h(int32_t a, uint32_t pk) // a * sext(half HALF of pk)
 {
@@ -156,13 +169,13 @@ __device__ __forceinline__ float cvtf_h(uint32_t pk) // float(sext(half))
     return r;
 }
 template <int HALF>
-__device__ __forceinline__ int32_t ashr_h(int32_t s, uint32_t pk) // sext(half) >> s
+__device__ __forceinline__ int32_t ashr_h(int32_t s, uint32_t pk) // sext(half) >> s, s wave-uniform (an SGPR operand)
 {
     int32_t r;
     if (HALF == 0)
-        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(s), "v"(pk));
+        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(s), "v"(pk));
     else
-        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(s), "v"(pk));
+        asm("v_ashrrev_i32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(s), "v"(pk));
     return r;
 }
 
@@ -279,10 +292,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     // its arithmetic phases instead of one burst at the top of every tile (32 KB per tile and workgroup outstanding for a third
     // of the tile's time is all that two workgroups per CU had in flight: ~3 TB/s by Little's law, which is what it ran at)
     v2i uq[NU][4], sq[NU][4];
-    auto load_rows = [&](v2i(&dst)[NU][4], const int16_t *src, int64_t tl) {
-        int64_t b;
-        int t, nv;
-        tile_of<FT>(tl, sr, b, t, nv);
+    auto load_rows = [&](v2i(&dst)[NU][4], const int16_t *src, const TileWalk<FT> &tw) {
+        const int64_t b = tw.b;
+        const int t = tw.t(sr), nv = tw.nvalid(sr);
         const char *base = reinterpret_cast<const char *>(src + (b * a.L + t) * H); // wave-uniform
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -305,10 +317,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     constexpr bool XPRE = HID;
     constexpr int NX_MIN = 2 * (ITEMS / NTHR); // x loads every wave issues per tile (waves of the last round: two more)
     v2i xq[XPRE ? ROUNDS : 1][2];
-    auto load_x = [&](int64_t tl) {
-        int64_t b;
-        int t, nv;
-        tile_of<FT>(tl, sr, b, t, nv);
+    auto load_x = [&](const TileWalk<FT> &tw) {
+        const int64_t b = tw.b;
+        const int t = tw.t(sr), nv = tw.nvalid(sr);
         const char *xb = reinterpret_cast<const char *>(reinterpret_cast<const int16_t *>(a.xs) + (pair_word(b, t >> 3, 0, a.TB >> 1, P) << 1));
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
@@ -326,18 +337,19 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
             }
         }
     };
+    TileWalk<FT> walk((int64_t)blockIdx.x, sr, gridDim.x);
     if ((int64_t)blockIdx.x < tiles) {
-        if constexpr (XPRE) load_x(blockIdx.x);
-        if constexpr (!GBN) load_rows(uq, a.u, blockIdx.x);
-        load_rows(sq, a.skip, blockIdx.x);
+        if constexpr (XPRE) load_x(walk);
+        if constexpr (!GBN) load_rows(uq, a.u, walk);
+        load_rows(sq, a.skip, walk);
     }
     __syncthreads();
 
     prologue_loads_done();
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        int64_t b0;
-        int t0, nvalid;
-        tile_of<FT>(tile, sr, b0, t0, nvalid);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, walk.advance()) {
+        const int64_t b0 = walk.b;
+        const int t0 = walk.t(sr), nvalid = walk.nvalid(sr);
+        const TileWalk<FT> walk_next = walk.next();
         const int64_t n0 = b0 * a.L + t0;
         // wave-uniform base of this tile; everything below is a 32-bit byte offset from it (no 64-bit address arithmetic per
         // thread: the kernel sits at its register cap)
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
             }
         }
         if constexpr (XPRE) {
-            if (tile_next < tiles) load_x(tile_next);
+            if (tile_next < tiles) load_x(walk_next);
         }
         lds_barrier();
         if constexpr (HID) vm_wait<8>(uq); // newer: the last tile's stores, skip (and x(next), if there is a next tile)
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
             }
         }
         if constexpr (!GBN) {
-            if (tile_next < tiles) load_rows(uq, a.u, tile_next); // the first epilogue is done with u
+            if (tile_next < tiles) load_rows(uq, a.u, walk_next); // the first epilogue is done with u
         }
         lds_barrier();
         if constexpr (HID) { // newer: x(next) and u(next), if there is a next tile
@@ -557,8 +569,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                         gp = pk_add_sat(gp, (uint32_t)bp[q]);
                         const int32_t r0 = sigd[ashr_h<0>(dsh, gp) + dbias], r1 = sigd[ashr_h<1>(dsh, gp) + dbias];
                         uint32_t lp = x1p[u][2 * g + q];
-                        if (lq_l) lp = pk_mad_sat(lp, lm, 0u);      // uniform: change_cfg of the gate's l operand
-                        else if (lq_r) lp = pk_ashr(lp, lr);
+                        // change_cfg of the gate's l operand: a saturating left shift (x lm) or a right shift, never both -- applied
+                        // as both (x 1 and >> 0 are the identity) rather than behind two uniform branches per pair
+                        lp = pk_ashr_u(pk_mul_sat_u(lp, lm), lr);
                         const uint32_t zp = pk_cvt(asr(mul24_h<0>(r0, lp), a.rs_gate), asr(mul24_h<1>(r1, lp), a.rs_gate));
                         zo[q] = (int)zp;
                         const uint32_t sp = (uint32_t)sq[u][g][q];
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                 }
             }
         }
-        if (tile_next < tiles) load_rows(sq, a.skip, tile_next); // the second epilogue is done with skip
+        if (tile_next < tiles) load_rows(sq, a.skip, walk_next); // the second epilogue is done with skip
     }
     // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
     if (S16) {

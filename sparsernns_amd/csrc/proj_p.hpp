@@ -65,6 +65,29 @@ __device__ __forceinline__ void tile_of(int64_t tile, const StepRange &sr, int64
     nvalid = sr.t_len - tt < FT ? sr.t_len - tt : FT;
 }
 
+// The same walk without a division per tile: a workgroup's tiles are gridDim.x apart, so (sequence, tile within it) advances
+// by a fixed pair with one carry.  All wave-uniform scalar arithmetic (tile_of's 64-bit division by a run-time value is a
+// software routine of some forty instructions, and the tile kernels called it two or three times per tile).
+template <int FT = 64>
+struct TileWalk {
+    int tps, db, dti; // tiles per sequence; gridDim.x = db * tps + dti
+    int b, ti;        // current tile: sequence b, tile ti of it
+    __device__ __forceinline__ TileWalk(int64_t tile0, const StepRange &sr, unsigned step)
+    {
+        tps = (sr.t_len + FT - 1) / FT;
+        db = (int)(step / (unsigned)tps); dti = (int)(step % (unsigned)tps);
+        b = (int)((unsigned)tile0 / (unsigned)tps); ti = (int)((unsigned)tile0 % (unsigned)tps);
+    }
+    __device__ __forceinline__ void advance()
+    {
+        b += db; ti += dti;
+        if (ti >= tps) { ti -= tps; ++b; }
+    }
+    __device__ __forceinline__ TileWalk next() const { TileWalk n = *this; n.advance(); return n; }
+    __device__ __forceinline__ int t(const StepRange &sr) const { return sr.t_lo + ti * FT; }
+    __device__ __forceinline__ int nvalid(const StepRange &sr) const { const int left = sr.t_len - ti * FT; return left < FT ? left : FT; }
+};
+
 // SM (stream mode) 0: int32 scan-native items; 1: int16 items (the host has checked that every value fits: Bu bits minus
 // the shift to the state exponent <= 16; one item is then 8 bytes); 2: the pair kernel's K stream (scan_quad.hpp):
 // K = (Bu << 16) + k in pair-native order, one 16-byte item per producer lane; 3: the LDS-fed pair kernel's int16 Bu
@@ -99,10 +122,9 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
     int64_t tile = blockIdx.x;
 
     v4i raw[NV];
-    auto fetch = [&](int64_t tl) {
-        int64_t b;
-        int t, nv;
-        tile_of(tl, sr, b, t, nv);
+    auto fetch = [&](const TileWalk<FT> &tw) {
+        const int64_t b = tw.b;
+        const int t = tw.t(sr), nv = tw.nvalid(sr);
         const char *xb = reinterpret_cast<const char *>(a.x + (b * a.L + t) * H); // wave-uniform; 32-bit byte offsets from here
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -112,7 +134,8 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
             raw[i] = *reinterpret_cast<const v4i *>(xb + 2u * (unsigned)(f * H + 8 * (v % VPF)));
         }
     };
-    if (tile < tiles) fetch(tile);
+    TileWalk<FT> walk(tile, sr, gridDim.x);
+    if (tile < tiles) fetch(walk);
     // this wave's weight columns (B operand) and per-channel constants stay in registers
     v4i wreg[NCT][KS];
     int32_t csv[NCT];
@@ -156,10 +179,9 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
     __syncthreads();
 
     prologue_loads_done();
-    for (int it = 0; tile < tiles; tile += gridDim.x, ++it) {
-        int64_t b0;
-        int t0, nvalid;
-        tile_of(tile, sr, b0, t0, nvalid);
+    for (int it = 0; tile < tiles; tile += gridDim.x, ++it, walk.advance()) {
+        const int64_t b0 = walk.b;
+        const int t0 = walk.t(sr), nvalid = walk.nvalid(sr);
         const int64_t n0 = b0 * a.L + t0;
         char *ub = reinterpret_cast<char *>(a.u + n0 * H); // wave-uniform base of this tile's rows of u
         int8_t *xh = Xh + (it & 1) * PLANE, *xl = Xl + (it & 1) * PLANE;
@@ -190,7 +212,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
             *reinterpret_cast<v2i *>(xh + f * KP + 8 * og) = hi;
             *reinterpret_cast<v2i *>(xl + f * KP + 8 * og) = lo;
         }
-        if (tile + gridDim.x < tiles) fetch(tile + gridDim.x); // in flight during phase B
+        if (tile + gridDim.x < tiles) fetch(walk.next()); // in flight during phase B
         __syncthreads();
         // ---- phase B: this wave's column tile(s), both 32-frame halves
 #pragma unroll
