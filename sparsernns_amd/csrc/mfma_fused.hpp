@@ -210,6 +210,11 @@ template <int KS, int NT, bool TRACE, bool S16 = false, bool DIRECT = false, int
 #ifndef S5_CGATE_HID
 #define S5_CGATE_HID 0
 #endif
+// -DS5_CGATE_COAL=0: u, skip and z move between registers and memory in the MFMA accumulator's layout (lane = frame: every
+// load / store instruction touches 64 rows with 8 bytes each) instead of through the LDS tiles described at COAL below
+#ifndef S5_CGATE_COAL
+#define S5_CGATE_COAL 1
+#endif
 #ifndef S5_CGATE_LB
 #define S5_CGATE_LB 4
 #endif
@@ -238,6 +243,15 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     int8_t *Sl = Sbase, *Sh = Sbase + (NPL - 1) * FT * KPS, *Xh = Sbase + NPL * FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     int32_t *bntab = reinterpret_cast<int32_t *>(red + 48); // GBN: 4 * H BatchNorm operands (bn16_setup)
+    // COAL: u and skip come in, and z goes out, as whole rows -- 16 bytes per lane, a wave instruction covers 1 KB of
+    // consecutive addresses -- through two LDS tiles [frame][TROW]; the epilogues, whose lanes are FRAMES (the accumulator
+    // layout of the channel-major MFMA), pick their 8-byte (frame, four channels) pieces out of LDS.  In the accumulator's own
+    // layout every global load / store instruction touched 64 different rows with 8 bytes each: the bytes per batch are the
+    // same, the memory pipeline sees an eighth of the requests.  TROW: 8-byte reads by 32 lanes 200 bytes apart hit 32 bank pairs.
+    constexpr bool COAL = S5_CGATE_COAL && PK16 && !TRACE && !WIDE && !GBN && !HID;
+    constexpr int TROW = 2 * H + 8, VPF = H / 8, NVC = FT * VPF / NTHR; // bytes per tile row; 16-byte vectors per frame / per thread
+    static_assert(!COAL || FT * VPF % NTHR == 0, "tile vectors per thread");
+    int8_t *Ut = reinterpret_cast<int8_t *>(red + 48), *St = Ut + FT * TROW; // u (then z) and skip of the current tile
     const int l = threadIdx.x & 63, r = l & 31, h = l >> 5, wave = threadIdx.x >> 6;
     const int ct = wave % NT, sub0 = wave / NT;
     const StepRange sr{a.t_lo, a.t_len};
@@ -292,6 +306,19 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     // its arithmetic phases instead of one burst at the top of every tile (32 KB per tile and workgroup outstanding for a third
     // of the tile's time is all that two workgroups per CU had in flight: ~3 TB/s by Little's law, which is what it ran at)
     v2i uq[NU][4], sq[NU][4];
+    v4i urow[COAL ? NVC : 1], srow[COAL ? NVC : 1]; // COAL: this thread's vectors of the NEXT tile's u and skip rows
+    auto load_tile = [&](v4i(&dst)[COAL ? NVC : 1], const int16_t *src, const TileWalk<FT> &tw) {
+        const int64_t b = tw.b;
+        const int t = tw.t(sr), nv = tw.nvalid(sr);
+        const char *base = reinterpret_cast<const char *>(src + (b * a.L + t) * H); // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int v = threadIdx.x + NTHR * i;
+            int f = v / VPF;
+            f = f < nv ? f : nv - 1;
+            dst[i] = *reinterpret_cast<const v4i *>(base + 2u * (unsigned)(f * H + 8 * (v % VPF)));
+        }
+    };
     auto load_rows = [&](v2i(&dst)[NU][4], const int16_t *src, const TileWalk<FT> &tw) {
         const int64_t b = tw.b;
         const int t = tw.t(sr), nv = tw.nvalid(sr);
@@ -340,10 +367,35 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     TileWalk<FT> walk((int64_t)blockIdx.x, sr, gridDim.x);
     if ((int64_t)blockIdx.x < tiles) {
         if constexpr (XPRE) load_x(walk);
-        if constexpr (!GBN) load_rows(uq, a.u, walk);
-        load_rows(sq, a.skip, walk);
+        if constexpr (COAL) {
+            load_tile(urow, a.u, walk);
+            load_tile(srow, a.skip, walk);
+        } else {
+            if constexpr (!GBN) load_rows(uq, a.u, walk);
+            load_rows(sq, a.skip, walk);
+        }
     }
     __syncthreads();
+    char *zb_prev = nullptr; // COAL: where the z tile still sitting in LDS belongs (the previous tile of this workgroup)
+    int nvalid_prev = 0;
+    // COAL: a thread moves the SAME vectors of the z tile out and of the u tile in, so the tile changes owner without a barrier
+    auto tiles_in_out = [&](bool incoming) {
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int v = threadIdx.x + NTHR * i, f = v / VPF, og = v % VPF;
+            int8_t *cu = Ut + f * TROW + 16 * og, *cs_ = St + f * TROW + 16 * og;
+            if (zb_prev) {
+                const v2i z0 = *reinterpret_cast<const v2i *>(cu), z1 = *reinterpret_cast<const v2i *>(cu + 8);
+                if (f < nvalid_prev) *reinterpret_cast<v4i *>(zb_prev + 2u * (unsigned)(f * H + 8 * og)) = v4i{z0[0], z0[1], z1[0], z1[1]};
+            }
+            if (incoming) {
+                *reinterpret_cast<v2i *>(cu) = v2i{urow[i][0], urow[i][1]};
+                *reinterpret_cast<v2i *>(cu + 8) = v2i{urow[i][2], urow[i][3]};
+                *reinterpret_cast<v2i *>(cs_) = v2i{srow[i][0], srow[i][1]};
+                *reinterpret_cast<v2i *>(cs_ + 8) = v2i{srow[i][2], srow[i][3]};
+            }
+        }
+    };
 
     prologue_loads_done();
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x, walk.advance()) {
@@ -356,6 +408,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
         char *zb = reinterpret_cast<char *>(a.z + n0 * H);
         const int64_t tile_next = tile + gridDim.x;
         if constexpr (HID) vm_wait<12>(xq); // newer than this tile's states: u, the last tile's stores, skip
+        if constexpr (COAL) tiles_in_out(true); // z of the previous tile out, u and skip of this one in
         // ---- phase A: stream items -> byte planes
 #pragma unroll
         for (int i = 0; i < ROUNDS; ++i) {
@@ -462,6 +515,12 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
         if constexpr (XPRE) {
             if (tile_next < tiles) load_x(walk_next);
         }
+        if constexpr (COAL) {
+            if (tile_next < tiles) { // the registers are free again: the next tile's rows, a whole tile ahead
+                load_tile(urow, a.u, walk_next);
+                load_tile(srow, a.skip, walk_next);
+            }
+        }
         lds_barrier();
         if constexpr (HID) vm_wait<8>(uq); // newer: the last tile's stores, skip (and x(next), if there is a next tile)
         // ---- phase B1: C projection + first epilogue
@@ -495,7 +554,9 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                         if constexpr (GBN) {
                             dup = pk_cvt(asr(__mul24(Dv[2 * q], ubn[2 * q]), a.rs_d), asr(__mul24(Dv[2 * q + 1], ubn[2 * q + 1]), a.rs_d));
                         } else {
-                            const uint32_t upk = (uint32_t)uq[u][g][q];
+                            uint32_t upk;
+                            if constexpr (COAL) upk = (uint32_t)(*reinterpret_cast<const v2i *>(Ut + (32 * sub + r) * TROW + 2 * (ch0 + 8 * g)))[q];
+                            else upk = (uint32_t)uq[u][g][q];
                             dup = pk_cvt(asr(mul24_h<0>(Dv[2 * q], upk), a.rs_d), asr(mul24_h<1>(Dv[2 * q + 1], upk), a.rs_d));
                         }
                         const uint32_t yp = pk_mad_sat(pk_sub_sat(crp, cip), 0x00020002u, dup); // 2*cx is not clipped, :765-767
@@ -532,7 +593,7 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
             }
         }
         if constexpr (!GBN) {
-            if (tile_next < tiles) load_rows(uq, a.u, walk_next); // the first epilogue is done with u
+            if (!COAL && tile_next < tiles) load_rows(uq, a.u, walk_next); // the first epilogue is done with u
         }
         lds_barrier();
         if constexpr (HID) { // newer: x(next) and u(next), if there is a next tile
@@ -574,11 +635,14 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                         lp = pk_ashr_u(pk_mul_sat_u(lp, lm), lr);
                         const uint32_t zp = pk_cvt(asr(mul24_h<0>(r0, lp), a.rs_gate), asr(mul24_h<1>(r1, lp), a.rs_gate));
                         zo[q] = (int)zp;
-                        const uint32_t sp = (uint32_t)sq[u][g][q];
+                        uint32_t sp;
+                        if constexpr (COAL) sp = (uint32_t)(*reinterpret_cast<const v2i *>(St + (32 * sub + r) * TROW + 2 * ch))[q];
+                        else sp = (uint32_t)sq[u][g][q];
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<0>(zp), kz, cvtf_h<0>(sp))));
                         mx[0] = fmaxf(mx[0], fabsf(__fmaf_rn(cvtf_h<1>(zp), kz, cvtf_h<1>(sp))));
                     }
-                    *reinterpret_cast<v2i *>(zb + 2u * (unsigned)((32 * sub + r) * H + ch)) = zo;
+                    if constexpr (COAL) *reinterpret_cast<v2i *>(Ut + (32 * sub + r) * TROW + 2 * ch) = zo; // u is done with: B1 is behind a barrier
+                    else *reinterpret_cast<v2i *>(zb + 2u * (unsigned)((32 * sub + r) * H + ch)) = zo;
                 }
             };
             if constexpr (PK16) {
@@ -641,8 +705,14 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
                 }
             }
         }
-        if (tile_next < tiles) load_rows(sq, a.skip, walk_next); // the second epilogue is done with skip
+        if constexpr (COAL) {
+            zb_prev = zb; nvalid_prev = nvalid;
+            lds_barrier(); // every wave's z pieces are in the tile, every wave is done with the skip tile
+        } else {
+            if (tile_next < tiles) load_rows(sq, a.skip, walk_next); // the second epilogue is done with skip
+        }
     }
+    if constexpr (COAL) tiles_in_out(false); // the last tile's z
     // ---- range flag and the three maxima (scaled back: power-of-two factors, exact)
     if (S16) {
         const int hi = pmax[0] > pmax[1] ? pmax[0] : pmax[1], lo = pmin[0] < pmin[1] ? pmin[0] : pmin[1];

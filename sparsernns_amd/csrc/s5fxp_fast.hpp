@@ -677,7 +677,8 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
             a.bn = bn;
             const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
-                                2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192 + (gate_bn ? 16 * (size_t)H : 0);
+                                2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192 + (gate_bn ? 16 * (size_t)H : 0) +
+                                (pk16 && !gate_bn ? 2 * 64 * (size_t)(2 * H + 8) : 0); // + the u / skip / z tiles (mfma_fused.hpp COAL)
             if (exact) {
                 // S5FXP_FWD_EXACT: the exact kernels below are the only ones; raise their gate
                 for (int g = 0; g < G; ++g)
