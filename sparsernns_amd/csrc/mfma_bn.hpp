@@ -376,6 +376,7 @@ struct Bn16 {
     int32_t has_sc, rs3, b3;
     int32_t has_b, shx4, tb4, l4, r4, b4b;
     int32_t cl, cr, cbits;
+    fxp::SatB sxb, s1, s2, s3, stb4, s4b, scb; // the clip bounds of the chain, resident in VGPRs (fxp_prims.hpp sat_bounds)
 };
 
 // builds the LDS tables (all threads) and returns the scalars; call before a __syncthreads()
@@ -399,6 +400,11 @@ __device__ __forceinline__ Bn16 bn16_setup(const BnArgs &a, const LayerDyn &d, i
     const int de = a.ue - d.bn_e;
     p.cl = de > 0 ? de : 0; p.cr = de < 0 ? -de : 0;
     p.cbits = a.out_bits < a.ub ? a.out_bits : a.ub;
+    p.sxb = fxp::sat_bounds(p.xb); p.s1 = fxp::sat_bounds(p.b1); p.s2 = fxp::sat_bounds(p.b2);
+    p.scb = fxp::sat_bounds(p.cbits);
+    // (the scale / bias stages are rare: their bounds are only made when the stages exist)
+    if (p.has_sc) p.s3 = fxp::sat_bounds(p.b3);
+    if (p.has_b) { p.stb4 = fxp::sat_bounds(p.tb4); p.s4b = fxp::sat_bounds(p.b4b); }
     return p;
 }
 
@@ -409,15 +415,22 @@ __device__ __forceinline__ void bn16_x4(const Bn16 &p, const int32_t (&x)[4], in
     v4i s4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0};
     if (p.has_sc) s4 = *reinterpret_cast<const v4i *>(p.sc + h0);
     if (p.has_b) b4 = *reinterpret_cast<const v4i *>(p.b4 + h0);
+    // stage by stage over the four channels: the two optional stages cost one uniform branch per call, not one per element
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        int32_t v = sat(asr(wshl(wadd(sat(wshl(x[e], p.shx1), p.xb), m4[e]), p.l1), p.r1), p.b1);
-        v = sat(asr(__mul24(v, i4[e]), p.rs2), p.b2);
-        if (p.has_sc) v = sat(asr(__mul24(v, s4[e]), p.rs3), p.b3);
-        if (p.has_b) v = sat(asr(wshl(wadd(sat(wshl(v, p.shx4), p.tb4), b4[e]), p.l4), p.r4), p.b4b);
-        t[e] = v;
-        u[e] = sat(asr(wshl(v, p.cl), p.cr), p.cbits);
+        const int32_t v = sat(asr(wshl(wadd(sat(wshl(x[e], p.shx1), p.sxb), m4[e]), p.l1), p.r1), p.s1);
+        t[e] = sat(asr(__mul24(v, i4[e]), p.rs2), p.s2);
     }
+    if (p.has_sc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = sat(asr(__mul24(t[e], s4[e]), p.rs3), p.s3);
+    }
+    if (p.has_b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = sat(asr(wshl(wadd(sat(wshl(t[e], p.shx4), p.stb4), b4[e]), p.l4), p.r4), p.s4b);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = sat(asr(wshl(t[e], p.cl), p.cr), p.scb);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
             const int cc = SM >= 2 ? (r >> 4) : (col >= PC ? 1 : 0), p = SM >= 2 ? 16 * (wct + NC * c) + (r & 15) : col - cc * PC;
             const int rs = cc ? a.rs_im : a.rs_re, bits = cc ? a.bim_bits : a.bre_bits, sh = cc ? a.sh_im : a.sh_re;
             const int lsh = sh < 0 ? -sh : 0, rsh = sh > 0 ? sh : 0;
+            SatB sbu; // this lane's clip bounds (re or im width), pinned in registers: not recomputed per element
+            sbu.hi = (int32_t)((1u << (bits - 1)) - 1u); sbu.lo = ~sbu.hi;
+            asm volatile("" : "+v"(sbu.lo), "+v"(sbu.hi));
 #pragma unroll
             for (int sub0 = 0; sub0 < 2; sub0 += SUB0_STEP) {
                 const int sub = sub0 + wsub;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64 * NT, 4) void k_bproj_p(BprojM2Args a, GroupOff 
                         v4i q;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int32_t bu = sat(asr(acc[4 * g + e], rs), bits);
+                            const int32_t bu = sat(asr(acc[4 * g + e], rs), sbu);
                             q[e] = asr(wshl(bu, lsh), rsh);
                             if (TRACE && o + e < nvalid) {
                                 if (!cc && a.tr_bu_re) a.tr_bu_re[(n0 + o + e) * PC + p] = bu;
