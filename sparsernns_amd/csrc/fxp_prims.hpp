@@ -140,4 +140,24 @@ __device__ __forceinline__ int32_t add_cb_apply(int32_t x, int xb, int32_t y, in
     return sat(s, ob);
 }
 
+// add_cb_apply with the operands' and the result's clip bounds resident in VGPRs (sat_bounds) and the uniform shift decisions
+// taken once: what the residual pass and the decoder's fused residual run per element
+struct AddCbV {
+    int32_t shx, shy, lsh, rsh; // left shifts of the operands to agg_exp; the result's left / right shift
+    SatB sx, sy, so;
+};
+__device__ __forceinline__ AddCbV make_add_cb_v(const AddCb &p, int xb, int yb, int ob)
+{
+    AddCbV v;
+    v.shx = p.shx; v.shy = p.shy; v.lsh = p.post > 0 ? p.post : 0; v.rsh = p.post < 0 ? -p.post : 0;
+    v.sx = sat_bounds(p.shx ? xb : 32); v.sy = sat_bounds(p.shy ? yb : 32); v.so = sat_bounds(ob);
+    return v;
+}
+__device__ __forceinline__ int32_t add_cb_apply(int32_t x, int32_t y, const AddCbV &p)
+{
+    // a shift of 0 with 32-bit bounds is the identity: the same value as the branches of add_cb_apply above
+    const int32_t a = sat(wshl(x, p.shx), p.sx), b = sat(wshl(y, p.shy), p.sy);
+    return sat(asr(wshl(wadd(a, b), p.lsh), p.rsh), p.so);
+}
+
 } // namespace fxp

@@ -286,6 +286,8 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
             p = hd.d->res;
         }
     }
+    AddCbV pv{};
+    if constexpr (RESID) pv = make_add_cb_v(p, res_bits, skip_bits, res_bits);
     int32_t lo[8], hi[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(RESID_THREADS, 5) void k_resid_minmax16(const int16
                     const unsigned o = toff + (unsigned)(i0 / R) * kstep + (unsigned)k * kstep;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const int32_t rr = add_cb_apply(v[e], res_bits, s[e], skip_bits, p, res_bits);
+                        const int32_t rr = add_cb_apply(v[e], s[e], pv);
                         if (tr_resid) tr_resid[lo_n * H + (o >> 1) + e] = rr;
                         v[e] = rr < 0 ? 0 : rr;
                     }

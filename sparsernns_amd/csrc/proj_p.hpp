@@ -326,7 +326,8 @@ using v2u16 = __attribute__((ext_vector_type(2))) unsigned short;
 
 struct CfgOp {
     int l, r, b;
-    __device__ __forceinline__ int32_t operator()(int32_t d) const { return sat(asr(wshl(d, l), r), b); }
+    SatB sb; // the clip bounds in VGPRs (fxp_prims.hpp sat_bounds): make_cfg is called once per kernel
+    __device__ __forceinline__ int32_t operator()(int32_t d) const { return sat(asr(wshl(d, l), r), sb); }
 };
 __device__ __forceinline__ CfgOp make_cfg(bool on, int bits, int e, int bits2, int e2)
 {
@@ -335,6 +336,7 @@ __device__ __forceinline__ CfgOp make_cfg(bool on, int bits, int e, int bits2, i
     c.r = on && e > e2 ? e - e2 : 0;
     const int b1 = on && e2 != e ? bits : 32, b2 = on && bits > bits2 ? bits2 : 32;
     c.b = b1 < b2 ? b1 : b2;
+    c.sb = sat_bounds(c.b);
     return c;
 }
 
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(384, 3) void k_enc_p(EncArgs a, float *ext, int ext
         elo[i] = 0;
     }
     const CfgOp cv = make_cfg(a.conv != 0, a.xb, a.xe, a.inp_bits, a.inp_exp);
+    const SatB so = sat_bounds(a.out_bits);
     // rows wave, wave+6, ... of the tile.  Two workgroups of six waves per CU are three waves per SIMD whatever the kernel
     // does, so it may hold 168 registers: all of a tile's rows are requested a tile ahead (dim 0.5; the two-unit phase B
     // of dim 1.0 has no room for that: there the first RA rows are prefetched and the rest requested at the top of phase A).
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(384, 3) void k_enc_p(EncArgs a, float *ext, int ext
                 int32_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    int32_t v = sat(asr(acc[4 * g + e], a.rs), a.out_bits);
-                    v = sat(wadd(v, bv[e]), a.out_bits);
+                    int32_t v = sat(asr(acc[4 * g + e], a.rs), so);
+                    v = sat(wadd(v, bv[e]), so);
                     o[e] = v < 0 ? 0 : v;
                     // (v, 65535 - v) as a u16 pair; one packed max keeps both running extremes
                     const uint32_t t = (uint32_t)__umul24((unsigned)o[e], 0x10001u) ^ 0xffff0000u;
@@ -673,6 +676,9 @@ __global__ __launch_bounds__(384, KS == 6 && RESID ? 2 : 3) void k_dec_p(DecArgs
         rs = rs < 0 ? 0 : 31;
     }
     const CfgOp cv = make_cfg(conv, a.xb, xe0, a.inp_bits, a.inp_exp);
+    const SatB so = sat_bounds(a.out_bits);
+    AddCbV rpv{};
+    if constexpr (RESID) rpv = make_add_cb_v(rp, rz.res_bits, rz.skip_bits, rz.res_bits);
     v4i wreg[CPW][KS];
     int32_t csv[CPW], bev[CPW];
 #pragma unroll
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(384, KS == 6 && RESID ? 2 : 3) void k_dec_p(DecArgs
                 unpack8_i16(rawz[i], z);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int32_t rr = add_cb_apply(z[e], rz.res_bits, x[e], rz.skip_bits, rp, rz.res_bits);
+                    const int32_t rr = add_cb_apply(z[e], x[e], rpv);
                     x[e] = rr < 0 ? 0 : rr;
                 }
             }
@@ -760,8 +766,8 @@ __global__ __launch_bounds__(384, KS == 6 && RESID ? 2 : 3) void k_dec_p(DecArgs
                 char *yp = yl; // a running pointer: sixteen hoisted offsets per column tile would cost the kernel its occupancy
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { // frames (i & 3) + 8 * (i >> 2)
-                    const int32_t v = sat(asr(acc[i], rs), a.out_bits);
-                    *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), a.out_bits);
+                    const int32_t v = sat(asr(acc[i], rs), so);
+                    *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), so);
                     yp += (i & 3) == 3 ? 5 * ystep : ystep;
                 }
             } else {
@@ -770,8 +776,8 @@ __global__ __launch_bounds__(384, KS == 6 && RESID ? 2 : 3) void k_dec_p(DecArgs
                 for (int i = 0; i < 16; ++i) {
                     const int fo = (i & 3) + 8 * (i >> 2);
                     if (nb + fo < a.N) {
-                        const int32_t v = sat(asr(acc[i], rs), a.out_bits);
-                        *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), a.out_bits);
+                        const int32_t v = sat(asr(acc[i], rs), so);
+                        *reinterpret_cast<int32_t *>(yp) = sat(wadd(v, bev[c]), so);
                     }
                     yp += (i & 3) == 3 ? 5 * ystep : ystep;
                 }
