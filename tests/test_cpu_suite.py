@@ -586,3 +586,13 @@ def test_pickle_converter_reads_array_trees_only(tmp_path):
     from sparsernns_amd import fxprun
     ex, meta = fxprun.load_export(str(tmp_path / "e.npz"), str(tmp_path / "e.json"))
     tree_equal(ex["params"], m.export()["params"], "params")
+
+
+def test_hand_written_wait_counts_match_the_compiled_store_counts():
+    """proj_p.hpp k_enc_p / k_dec_p prefetch with loads the compiler cannot see and wait with s_waitcnt vmcnt(N), N = the store
+    instructions a wave issues per full tile (scan_quad.hpp vm_wait).  That is only right while the compiler emits exactly
+    those stores: tools/check_vmwait.py compiles the device code to assembly (no GPU) and counts."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_vmwait.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
