@@ -286,7 +286,8 @@ int s5fxp_model_forward(const s5fxp_model *m, const int32_t *x, int x_bits, int 
  *   S5FXP_NO_DEC_RESID                                         the last layer's residual pass as a launch of its own
  *   S5FXP_NO_LIVE_LANES                                        a compacted layer's recurrence streams keep their padding slots
  *   S5FXP_GATE_BN                                              the gate kernel recomputes the SSM input u instead of reading it (slower)
- *   S5FXP_CGATE_FT32                                           the gate kernel on 32-frame tiles, three-wave workgroups (no faster)
+ *   S5FXP_CGATE_FT64, S5FXP_WGS_CGATE32=n                      the gate kernel on 64-frame tiles (six-wave workgroups) / workgroups per launch
+ *                                                              of the default 32-frame form
  *   S5FXP_WGS_ENC|DEC|CGATE|BPROJ|RESID=n                      workgroups per launch of the tile kernels
  *   S5FXP_PLANE_SKEW=bytes                                     extra distance between the workspace's planes (multiple of 256)
  *   S5FXP_DEBUG_SYNC                                           synchronise and check after every stage of a forward

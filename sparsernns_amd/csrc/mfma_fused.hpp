@@ -181,6 +181,7 @@ __device__ __forceinline__ int32_t ashr_h(int32_t s, uint32_t pk) // sext(half) 
 
 constexpr int SIGTAB_WORDS = 2 * 7 * 64; // sig_x <= 6 on this path (host-checked)
 constexpr int SIGDIR_MAX_BITS = 12, SIGDIR_BYTES = 2 << SIGDIR_MAX_BITS;
+__host__ __device__ __forceinline__ int sigdir_lds_bytes(int bits) { return ((2 << bits) + 15) & ~15; }
 
 // S16: the state stream holds int16, written with saturation by k_scan_quad_asm16 (a.xmax <= 32766 then: a saturated
 // state fails the range check like any other state beyond the bound)
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(FTP * 2 * NT, NT <= 3 && KS == 1 && !WIDE ? S5_CGAT
     int32_t *sigt = lutp + 8; // SIGTAB_WORDS, or the direct table (int16, SIGDIR_BYTES)
     const int16_t *sigd = reinterpret_cast<const int16_t *>(sigt);
     constexpr int NPL = WIDE ? 4 : 2; // byte planes of the state operand; plane NPL-1 is the signed top byte
-    int8_t *Sbase = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? SIGDIR_BYTES : 4 * SIGTAB_WORDS);
+    // the direct table takes what it needs (2 bytes x 2^sigdir_bits, to a multiple of 16), not the 8 KB of its widest form
+    int8_t *Sbase = reinterpret_cast<int8_t *>(sigt) + (DIRECT ? sigdir_lds_bytes(a.sigdir_bits) : 4 * SIGTAB_WORDS);
     int8_t *Sl = Sbase, *Sh = Sbase + (NPL - 1) * FT * KPS, *Xh = Sbase + NPL * FT * KPS, *Xl = Xh + FT * KPX;
     float *red = reinterpret_cast<float *>(Xl + FT * KPX);
     int32_t *bntab = reinterpret_cast<int32_t *>(red + 48); // GBN: 4 * H BatchNorm operands (bn16_setup)

@@ -317,7 +317,9 @@ struct ModelCfg {
     bool no_live_lanes = false; // S5FXP_NO_LIVE_LANES: the recurrence streams of a compacted layer keep their padding slots
     bool gate_bn = false;      // S5FXP_GATE_BN: the gate kernel recomputes u = BatchNorm(layer input) instead of reading it (k_cgate_p<.., GBN>;
                                // measured slower: DESIGN.md 4a)
-    bool cgate_ft32 = false;   // S5FXP_CGATE_FT32: the gate kernel on 32-frame tiles with three-wave workgroups (experiment)
+    bool cgate_ft64 = false;   // S5FXP_CGATE_FT64: the packed-epilogue gate kernel on 64-frame tiles with six-wave workgroups (the form before
+                               // the 32-frame / three-wave one became the default at dim_scale 0.5)
+    int64_t cap_cgate32 = 1280; // S5FXP_WGS_CGATE32: workgroups per launch of the 32-frame gate kernel (5 per CU: all resident)
     bool no_dec_resid = false; // S5FXP_NO_DEC_RESID: the last layer's residual pass as its own launch (proj_p.hpp k_dec_p<.., RESID>)
     int pairl_blocks = 32;    // S5FXP_PAIRL_BLOCKS=16: 16 time blocks per LDS buffer of the LDS-fed pair kernel
     size_t plane_skew = 0;    // S5FXP_PLANE_SKEW=<bytes, multiple of 256>: extra distance between the workspace's planes (experiments)
@@ -332,7 +334,7 @@ struct ModelCfg {
             return (int64_t)(v > 0 ? v : dflt);
         };
         c.debug_sync = on("S5FXP_DEBUG_SYNC"); c.no_bn_ext = on("S5FXP_NO_BN_EXT"); c.no_pair = on("S5FXP_NO_PAIR");
-        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT"); c.no_dec_resid = on("S5FXP_NO_DEC_RESID"); c.no_live_lanes = on("S5FXP_NO_LIVE_LANES"); c.gate_bn = on("S5FXP_GATE_BN"); c.cgate_ft32 = on("S5FXP_CGATE_FT32");
+        c.pair_global = on("S5FXP_PAIR_GLOBAL"); c.no_pk16 = on("S5FXP_NO_PK16"); c.no_compact = on("S5FXP_NO_COMPACT"); c.no_dec_resid = on("S5FXP_NO_DEC_RESID"); c.no_live_lanes = on("S5FXP_NO_LIVE_LANES"); c.gate_bn = on("S5FXP_GATE_BN"); c.cgate_ft64 = on("S5FXP_CGATE_FT64"); c.cap_cgate32 = cap("S5FXP_WGS_CGATE32", c.cap_cgate32);
         { const char *e = std::getenv("S5FXP_PAIRL_BLOCKS"); c.pairl_blocks = e && std::atoi(e) == 16 ? 16 : 32; }
         { const char *e = std::getenv("S5FXP_PLANE_SKEW"); c.plane_skew = e ? ((size_t)std::atoll(e) & ~(size_t)255) : 0; }
         c.cap_enc = cap("S5FXP_WGS_ENC", c.cap_enc); c.cap_dec = cap("S5FXP_WGS_DEC", c.cap_dec);

@@ -676,7 +676,7 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
             fused = true;
             a.bad_bits = ST_WIDE_STATE | (defer ? ST_REDO : 0);
             a.bn = bn;
-            const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
+            const size_t smem = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)sigdir_lds_bytes(fl.sigdir_bits) : 4 * (size_t)SIGTAB_WORDS) +
                                 2 * 64 * (size_t)(2 * P + 16) + 2 * 64 * (size_t)(H + 16) + 192 + (gate_bn ? 16 * (size_t)H : 0) +
                                 (pk16 && !gate_bn ? 2 * 64 * (size_t)(2 * H + 8) : 0); // + the u / skip / z tiles (mfma_fused.hpp COAL)
             if (exact) {
@@ -697,12 +697,17 @@ int forward_fast(const s5fxp_model *m, const int32_t *x, int x_bits, int x_exp, 
                             if (compact && P == 32) launch_gate(k_cgate_p<1, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                             else if (compact) launch_gate(k_cgate_p<2, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
                             else launch_gate(k_cgate_p<4, 6, false, S16_, DIR_, 64, false, PAIR_, PK_>, cg, smem, a, 768);
-                        } else if (PK_ && PAIR_ && compact && cfg.cgate_ft32 && !gate_bn) {
-                            // experiment (S5FXP_CGATE_FT32): 32-frame tiles, three-wave workgroups -- twice as many independent barrier groups per CU
-                            const size_t smem32 = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)SIGDIR_BYTES : 4 * (size_t)SIGTAB_WORDS) +
+                        } else if (PK_ && !cfg.cgate_ft64 && !gate_bn) {
+                            // 32-frame tiles, three-wave workgroups: with the sigmoid table sized exactly FIVE of them fit a CU's LDS and
+                            // registers -- 15 waves instead of the 12 of two six-wave workgroups, for a kernel whose waves wait two thirds
+                            // of their cycles.  The grid is exactly what is resident at once (5 x 256 CUs): 170 us per 8-batch launch
+                            // against 190 (tools/ab_cgate_ft32.sh; 1024 or 1536 workgroups: 189 / 209).
+                            const size_t smem32 = 5 * (size_t)H * 4 + 32 + (direct ? (size_t)sigdir_lds_bytes(fl.sigdir_bits) : 4 * (size_t)SIGTAB_WORDS) +
                                                   2 * 32 * (size_t)(2 * P + 16) + 2 * 32 * (size_t)(H + 16) + 192 + 2 * 32 * (size_t)(2 * H + 8);
-                            const int64_t tl32 = (int64_t)B * ((L + 31) / 32), cap32 = 2 * cap_cgate, per32 = (tl32 + cap32 - 1) / cap32;
-                            launch_gate(k_cgate_p<1, 3, false, S16_, DIR_, 32, false, PAIR_, PK_>, (unsigned)((tl32 + per32 - 1) / per32), smem32, a, 192);
+                            const int64_t tl32 = (int64_t)B * ((L + 31) / 32), cap32 = std::max<int64_t>(cfg.cap_cgate32 / G, 1), per32 = (tl32 + cap32 - 1) / cap32;
+                            const unsigned g32 = (unsigned)((tl32 + per32 - 1) / per32);
+                            if (compact) launch_gate(k_cgate_p<1, 3, false, S16_, DIR_, 32, false, PAIR_, PK_>, g32, smem32, a, 192);
+                            else launch_gate(k_cgate_p<2, 3, false, S16_, DIR_, 32, false, PAIR_, PK_>, g32, smem32, a, 192);
                         } else if (PK_ && gate_bn) {
                             if (compact) launch_gate(k_cgate_p<1, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
                             else launch_gate(k_cgate_p<2, 3, false, S16_, DIR_, 64, false, PAIR_, PK_, PK_>, cg, smem, a);
